@@ -1,0 +1,134 @@
+"""ctypes binding of the okrt C ABI (include/okrt.h).
+
+`DeviceLibrary` binds the product, libokrt.so (HIP, gfx950). It fails loudly when the shared
+library is missing or does not export every symbol the header declares: there is no CPU fallback
+in the product. The same signature table binds the oracle's `okrt_oracle_*` twins for tests
+(`bind(lib, prefix)`), which is why it lives here.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+
+OKRT_ABI_VERSION = 1
+
+# okrt_table slots = the reference's t-registers (ShaderResourceRegisters.h:9-21)
+TABLE_TRI_POS, TABLE_TRI_INFO, TABLE_BVH = 0, 1, 2
+TABLE_OCT, TABLE_SPHERE, TABLE_MESH = 5, 6, 7
+TABLE_DIR_LIGHT, TABLE_POINT_LIGHT, TABLE_SPOT_LIGHT = 8, 9, 10
+TABLE_STRIDE = {0: 36, 1: 132, 2: 36, 5: 48, 6: 84, 7: 232, 8: 32, 9: 32, 10: 48}
+
+OPT_TRAVERSAL, OPT_MAX_BOUNCES, OPT_COUNTERS, OPT_TIMING = 0, 1, 2, 3
+TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
+
+
+class RenderData(C.Structure):
+    """b0 cbuffer, 240 bytes (RaytracerCS.hlsl:19-47)."""
+    _fields_ = [
+        ("accumulationEnabled", C.c_uint32), ("numAccumulationFrames", C.c_uint32),
+        ("numSpheres", C.c_uint32), ("numMeshes", C.c_uint32),
+        ("numDirLights", C.c_uint32), ("numPointLights", C.c_uint32), ("numSpotLights", C.c_uint32),
+        ("debugMode", C.c_uint32),
+        ("textureDims", C.c_uint32 * 2), ("viewPlaneDims", C.c_float * 2),
+        ("cameraInverseProjectionMatrix", C.c_float * 16), ("cameraInverseViewMatrix", C.c_float * 16),
+        ("cameraPosition", C.c_float * 3), ("cameraNearZ", C.c_float),
+        ("cameraUpDir", C.c_float * 3), ("dofStrength", C.c_float),
+        ("cameraRightDir", C.c_float * 3), ("dofDistance", C.c_float),
+        ("debugMaxCount", C.c_uint32), ("pad0", C.c_float * 3),
+    ]
+
+
+assert C.sizeof(RenderData) == 240
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "pixels", "segments", "n_oct", "n_mesh", "n_node", "n_tri", "mesh_hits", "sphere_hits",
+        "tex_taps", "env_taps", "fast_nodes", "fast_tris")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+P = C.c_void_p
+U32 = C.c_uint32
+# name -> (restype, argtypes); every symbol include/okrt.h declares (minus okrt_create/get_api,
+# which differ between product and oracle and are bound separately).
+SIGNATURES = {
+    "destroy": (C.c_int, [P]),
+    "last_error": (C.c_char_p, [P]),
+    "set_table": (C.c_int, [P, C.c_int, P, U32, U32]),
+    "set_textures": (C.c_int, [P, P, U32, U32, U32]),
+    "set_envmap": (C.c_int, [P, P, U32]),
+    "scale_texture_rgba8": (C.c_int, [P, P, U32, U32, P, U32, U32]),
+    "resize": (C.c_int, [P, U32, U32]),
+    "set_tile": (C.c_int, [P, U32, U32, U32]),
+    "tile_rows": (C.c_int, [P, C.POINTER(U32)]),
+    "reset_accumulation": (C.c_int, [P]),
+    "render": (C.c_int, [P, C.POINTER(RenderData)]),
+    "synchronize": (C.c_int, [P]),
+    "read_result_rgba8": (C.c_int, [P, P]),
+    "read_accum_f32x4": (C.c_int, [P, P]),
+    "set_option": (C.c_int, [P, C.c_int, C.c_int64]),
+    "get_counters": (C.c_int, [P, C.POINTER(Counters)]),
+    "reset_counters": (C.c_int, [P]),
+}
+# product-only entry points
+PRODUCT_ONLY = {
+    "abi_version": (C.c_int, []),
+    "create": (C.c_int, [C.c_int, C.POINTER(P)]),
+    "bind_framebuffers": (C.c_int, [P, P, P]),
+    "set_stream": (C.c_int, [P, P]),
+    "timer_begin": (C.c_int, [P]),
+    "timer_end": (C.c_int, [P]),
+    "timer_elapsed_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
+    "last_render_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
+    "get_api": (P, []),
+}
+HEADER_SYMBOLS = ["okrt_" + n for n in list(SIGNATURES) + list(PRODUCT_ONLY)]
+
+
+class OkrtError(RuntimeError):
+    pass
+
+
+class _Bound:
+    """Functions of one library, reachable as attributes without their prefix."""
+
+    def __init__(self, lib, prefix, table):
+        self._lib = lib
+        for name, (res, args) in table.items():
+            fn = getattr(lib, prefix + name)  # AttributeError if the library lacks the symbol
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+
+def bind(lib, prefix, extra=None):
+    table = dict(SIGNATURES)
+    if extra:
+        table.update(extra)
+    return _Bound(lib, prefix, table)
+
+
+def device_library_path():
+    return os.path.join(PKG_DIR, "libokrt.so")
+
+
+_device = None
+
+
+def load_device_library():
+    """Load libokrt.so (the HIP product). Raises if it is not built; never falls back."""
+    global _device
+    if _device is None:
+        path = device_library_path()
+        if not os.path.exists(path):
+            raise OkrtError(f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()')")
+        lib = C.CDLL(path)
+        fns = bind(lib, "okrt_", PRODUCT_ONLY)
+        if fns.abi_version() != OKRT_ABI_VERSION:
+            raise OkrtError("libokrt.so ABI version mismatch")
+        _device = fns
+    return _device

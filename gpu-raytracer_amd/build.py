@@ -1,0 +1,63 @@
+"""Build recipe for the native libraries (all in-tree; the .so files travel with the snapshot).
+
+  libokrt.so       hipcc --offload-arch=gfx950   csrc/*.hip          the HIP product
+  libokrt_host.so  g++                           host/*.cpp          C++ host layer
+  oracle/liboracle.so (+ oracle/_ref when /root/reference exists)    test infrastructure
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-class-memaccess"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, cwd=None):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, cwd=cwd, check=True)
+
+
+def build_device(force=False):
+    src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.cpp")))
+    deps = src + glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(REPO, "include", "okrt.h")]
+    out = os.path.join(PKG, "libokrt.so")
+    if force or _newer(out, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIP_FLAGS + ["-o", out] + src)
+    return out
+
+
+def build_host(force=False):
+    src = sorted(glob.glob(os.path.join(PKG, "host", "*.cpp")))
+    deps = src + glob.glob(os.path.join(PKG, "host", "*.h")) + [os.path.join(REPO, "include", "okrt.h")]
+    out = os.path.join(PKG, "libokrt_host.so")
+    if force or _newer(out, deps):
+        _run([os.environ.get("CXX", "g++")] + HOST_FLAGS + ["-o", out] + src)
+    return out
+
+
+def build_oracle():
+    _run(["make", "-C", os.path.join(REPO, "oracle"), "all"])
+    if os.path.isdir("/root/reference/source"):
+        _run(["make", "-C", os.path.join(REPO, "oracle"), "ref"])
+
+
+def build_all(force=False):
+    build_device(force)
+    build_host(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

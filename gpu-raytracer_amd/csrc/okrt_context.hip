@@ -1,0 +1,501 @@
+// okrt_context.hip — the C ABI of include/okrt.h over the HIP runtime: device memory for the
+// reference's tables (t0..t10), framebuffers (u0/u1), validation, options, counters, timing.
+// Replaces source/DirectX/DX11.cpp + source/Graphics/GPUStorage.* + RenderTexture for the compute
+// path of the reference (citations in include/okrt.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "okrt_fast.h"
+#include "okrt_kernels.h"
+
+using namespace okrt;
+
+namespace {
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct Table {
+    std::vector<uint8_t> host;  // retained copy: validation + derivation of the fast structure
+    DeviceBuffer dev;
+    uint32_t count = 0, stride = 0;
+};
+
+}  // namespace
+
+struct okrt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    Table tables[11];
+    DeviceBuffer textures, env;
+    uint32_t numTextures = 0, texW = 0, texH = 0, envFace = 0;
+    uint32_t W = 0, H = 0;
+    TileView tile{};
+    DeviceBuffer accumOwn, resultOwn;
+    float4* accum = nullptr;
+    uint32_t* result = nullptr;
+    DeviceBuffer counters;
+    bool countersOn = false, timingOn = false;
+    int traversal = OKRT_TRAVERSAL_FAST;
+    int maxBounces = 1;
+    bool tablesDirty = true;   // re-validate before the next render
+    bool tablesValid = false;
+    FastScene* fast = nullptr;  // derived structure (okrt_fast.h); rebuilt when geometry changes
+    bool fastDirty = true;
+    hipEvent_t evBegin = nullptr, evEnd = nullptr, evR0 = nullptr, evR1 = nullptr;
+    bool lastRenderTimed = false;
+    std::string err;
+};
+
+namespace {
+
+okrt_status fail(okrt_ctx* c, okrt_status s, const std::string& msg) {
+    if (c) c->err = msg;
+    return s;
+}
+#define OKRT_HIP(c, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(c, e_ == hipErrorOutOfMemory ? OKRT_ERR_OOM : OKRT_ERR_DEVICE,                       \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                  \
+    } while (0)
+
+okrt_status ensure(okrt_ctx* c, DeviceBuffer& b, size_t bytes) {
+    if (b.bytes == bytes && (b.ptr || !bytes)) return OKRT_OK;
+    if (b.ptr) {
+        OKRT_HIP(c, hipStreamSynchronize(c->stream));
+        OKRT_HIP(c, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    if (bytes) {
+        OKRT_HIP(c, hipMalloc(&b.ptr, bytes));
+        b.bytes = bytes;
+    }
+    return OKRT_OK;
+}
+
+uint32_t slotStride(okrt_table slot) {
+    switch (slot) {
+        case OKRT_TABLE_TRI_POS: return OKRT_SIZEOF_TRIANGLE;
+        case OKRT_TABLE_TRI_INFO: return OKRT_SIZEOF_TRIANGLE_INFO;
+        case OKRT_TABLE_BVH: return OKRT_SIZEOF_BVH_NODE;
+        case OKRT_TABLE_OCT: return OKRT_SIZEOF_OCT_NODE;
+        case OKRT_TABLE_SPHERE: return OKRT_SIZEOF_SPHERE;
+        case OKRT_TABLE_MESH: return OKRT_SIZEOF_MESH;
+        case OKRT_TABLE_DIR_LIGHT: return OKRT_SIZEOF_DIR_LIGHT;
+        case OKRT_TABLE_POINT_LIGHT: return OKRT_SIZEOF_POINT_LIGHT;
+        case OKRT_TABLE_SPOT_LIGHT: return OKRT_SIZEOF_SPOT_LIGHT;
+        default: return 0;
+    }
+}
+
+uint32_t ownedRows(uint32_t H, uint32_t stripeRows, uint32_t idx, uint32_t stride) {
+    uint32_t rows = 0;
+    for (uint32_t s = idx; (uint64_t)s * stripeRows < H; s += stride) rows += std::min<uint32_t>(stripeRows, H - s * stripeRows);
+    return rows;
+}
+
+okrt_status allocFramebuffers(okrt_ctx* c) {
+    size_t px = (size_t)c->tile.rows * c->W;
+    okrt_status s;
+    if ((s = ensure(c, c->accumOwn, px * sizeof(float4))) != OKRT_OK) return s;
+    if ((s = ensure(c, c->resultOwn, px * 4)) != OKRT_OK) return s;
+    c->accum = (float4*)c->accumOwn.ptr;
+    c->result = (uint32_t*)c->resultOwn.ptr;
+    if (px) {
+        OKRT_HIP(c, hipMemsetAsync(c->accum, 0, px * sizeof(float4), c->stream));
+        OKRT_HIP(c, hipMemsetAsync(c->result, 0, px * 4, c->stream));
+    }
+    return OKRT_OK;
+}
+
+// Every index a kernel will follow is checked on the host first: an out-of-range or cyclic table
+// would fault or hang the GPU. Children must come after their parent (true of every tree the
+// reference's builders emit: BvhBuilder.cpp:178-186, RayTracer.cpp:690-693), which rules out cycles.
+okrt_status validateTables(okrt_ctx* c) {
+    const Table& tp = c->tables[OKRT_TABLE_TRI_POS];
+    const Table& ti = c->tables[OKRT_TABLE_TRI_INFO];
+    const Table& bv = c->tables[OKRT_TABLE_BVH];
+    const Table& oc = c->tables[OKRT_TABLE_OCT];
+    const Table& me = c->tables[OKRT_TABLE_MESH];
+    const BvhNodeRec* nodes = (const BvhNodeRec*)bv.host.data();
+    for (uint32_t i = 0; i < bv.count; ++i) {
+        const BvhNodeRec& n = nodes[i];
+        if (n.firstChild != kInvalid) {
+            if (n.firstChild <= i || (uint64_t)n.firstChild + 1 >= bv.count) return fail(c, OKRT_ERR_RANGE, "BVH node " + std::to_string(i) + ": child index out of order or range");
+        } else if (n.triStart > n.triEnd || n.triEnd > tp.count) {
+            if (!(n.triStart == kInvalid && n.triEnd == kInvalid)) return fail(c, OKRT_ERR_RANGE, "BVH leaf " + std::to_string(i) + ": triangle range outside t0");
+        }
+    }
+    if (tp.count && ti.count < tp.count) return fail(c, OKRT_ERR_RANGE, "t1 (TriangleInfo) is shorter than t0 (Triangle)");
+    const MeshRec* meshes = (const MeshRec*)me.host.data();
+    for (uint32_t i = 0; i < me.count; ++i)
+        if (meshes[i].bvhNodeStartIdx >= bv.count) return fail(c, OKRT_ERR_RANGE, "mesh " + std::to_string(i) + ": bvhNodeStartIdx outside t2");
+    const OctNodeRec* oct = (const OctNodeRec*)oc.host.data();
+    for (uint32_t i = 0; i < oc.count; ++i) {
+        const OctNodeRec& n = oct[i];
+        if (n.meshesStart != n.meshesEnd && (n.meshesStart > n.meshesEnd || n.meshesEnd > me.count))
+            return fail(c, OKRT_ERR_RANGE, "octree node " + std::to_string(i) + ": instance range outside t7");
+        if (n.numChildren && (n.numChildren > 8 || n.firstChild <= i || (uint64_t)n.firstChild + n.numChildren > oc.count))
+            return fail(c, OKRT_ERR_RANGE, "octree node " + std::to_string(i) + ": child range out of order or range");
+    }
+    return OKRT_OK;
+}
+
+SceneView makeView(const okrt_ctx* c) {
+    SceneView s{};
+    s.triPos = (const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].dev.ptr;
+    s.triInfo = (const TriangleInfoRec*)c->tables[OKRT_TABLE_TRI_INFO].dev.ptr;
+    s.bvh = (const BvhNodeRec*)c->tables[OKRT_TABLE_BVH].dev.ptr;
+    s.textures = (const uint8_t*)c->textures.ptr;
+    s.env = (const uint8_t*)c->env.ptr;
+    s.oct = (const OctNodeRec*)c->tables[OKRT_TABLE_OCT].dev.ptr;
+    s.spheres = (const SphereRec*)c->tables[OKRT_TABLE_SPHERE].dev.ptr;
+    s.meshes = (const MeshRec*)c->tables[OKRT_TABLE_MESH].dev.ptr;
+    s.dirLights = (const DirLightRec*)c->tables[OKRT_TABLE_DIR_LIGHT].dev.ptr;
+    s.pointLights = (const PointLightRec*)c->tables[OKRT_TABLE_POINT_LIGHT].dev.ptr;
+    s.spotLights = (const SpotLightRec*)c->tables[OKRT_TABLE_SPOT_LIGHT].dev.ptr;
+    s.numOct = c->tables[OKRT_TABLE_OCT].count;
+    s.numTextures = c->numTextures;
+    s.texW = c->texW;
+    s.texH = c->texH;
+    s.envFace = c->envFace;
+    s.maxBounces = (uint32_t)c->maxBounces;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int okrt_abi_version(void) { return OKRT_ABI_VERSION; }
+
+okrt_status okrt_create(int device, okrt_ctx** out) {
+    if (!out) return OKRT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return OKRT_ERR_DEVICE;
+    okrt_ctx* c = new okrt_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return OKRT_ERR_DEVICE;
+    }
+    c->stream = c->ownStream;
+    hipEventCreate(&c->evBegin);
+    hipEventCreate(&c->evEnd);
+    hipEventCreate(&c->evR0);
+    hipEventCreate(&c->evR1);
+    if (hipMalloc(&c->counters.ptr, kNumCounters * sizeof(unsigned long long)) != hipSuccess) {
+        delete c;
+        return OKRT_ERR_OOM;
+    }
+    c->counters.bytes = kNumCounters * sizeof(unsigned long long);
+    hipMemsetAsync(c->counters.ptr, 0, c->counters.bytes, c->stream);
+    *out = c;
+    return OKRT_OK;
+}
+
+okrt_status okrt_destroy(okrt_ctx* c) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (Table& t : c->tables)
+        if (t.dev.ptr) hipFree(t.dev.ptr);
+    for (DeviceBuffer* b : {&c->textures, &c->env, &c->accumOwn, &c->resultOwn, &c->counters})
+        if (b->ptr) hipFree(b->ptr);
+    fastDestroy(c->fast);
+    for (hipEvent_t e : {c->evBegin, c->evEnd, c->evR0, c->evR1})
+        if (e) hipEventDestroy(e);
+    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    delete c;
+    return OKRT_OK;
+}
+
+const char* okrt_last_error(const okrt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint32_t elem_bytes, uint32_t count) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    uint32_t stride = slotStride(slot);
+    if (!stride) return fail(c, OKRT_ERR_INVALID_ARG, "set_table: unknown slot");
+    if (elem_bytes != stride) return fail(c, OKRT_ERR_INVALID_ARG, "set_table: element stride " + std::to_string(elem_bytes) + " != reference stride " + std::to_string(stride));
+    OKRT_HIP(c, hipSetDevice(c->device));
+    Table& t = c->tables[slot];
+    if (!data) count = 0;
+    size_t bytes = (size_t)count * stride;
+    okrt_status s = ensure(c, t.dev, bytes);
+    if (s != OKRT_OK) return s;
+    t.host.assign((const uint8_t*)data, (const uint8_t*)data + bytes);
+    t.count = count;
+    t.stride = stride;
+    if (bytes) {
+        // the previous contents may still be read by an in-flight frame on this stream: stream order
+        OKRT_HIP(c, hipMemcpyAsync(t.dev.ptr, t.host.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if (slot == OKRT_TABLE_TRI_POS || slot == OKRT_TABLE_TRI_INFO || slot == OKRT_TABLE_BVH || slot == OKRT_TABLE_OCT || slot == OKRT_TABLE_MESH) {
+        c->tablesDirty = true;
+        c->fastDirty = true;
+    }
+    return OKRT_OK;
+}
+
+okrt_status okrt_set_textures(okrt_ctx* c, const uint8_t* rgba8, uint32_t count, uint32_t width, uint32_t height) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    if (!rgba8 || !count || !width || !height) {
+        okrt_status s = ensure(c, c->textures, 0);
+        c->numTextures = c->texW = c->texH = 0;
+        return s;
+    }
+    size_t bytes = (size_t)count * width * height * 4;
+    okrt_status s = ensure(c, c->textures, bytes);
+    if (s != OKRT_OK) return s;
+    OKRT_HIP(c, hipMemcpyAsync(c->textures.ptr, rgba8, bytes, hipMemcpyHostToDevice, c->stream));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));  // the caller's buffer is copied by the time we return
+    c->numTextures = count;
+    c->texW = width;
+    c->texH = height;
+    return OKRT_OK;
+}
+
+okrt_status okrt_set_envmap(okrt_ctx* c, const uint8_t* faces, uint32_t face) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    if (!faces || !face) {
+        okrt_status s = ensure(c, c->env, 0);
+        c->envFace = 0;
+        return s;
+    }
+    size_t bytes = (size_t)6 * face * face * 4;
+    okrt_status s = ensure(c, c->env, bytes);
+    if (s != OKRT_OK) return s;
+    OKRT_HIP(c, hipMemcpyAsync(c->env.ptr, faces, bytes, hipMemcpyHostToDevice, c->stream));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    c->envFace = face;
+    return OKRT_OK;
+}
+
+okrt_status okrt_scale_texture_rgba8(okrt_ctx* c, const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh) {
+    if (!c || !src || !dst || !sw || !sh || !dw || !dh) return fail(c, OKRT_ERR_INVALID_ARG, "scale_texture: bad argument");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    void *dsrc = nullptr, *ddst = nullptr;
+    size_t sb = (size_t)sw * sh * 4, db = (size_t)dw * dh * 4;
+    OKRT_HIP(c, hipMalloc(&dsrc, sb));
+    hipError_t e = hipMalloc(&ddst, db);
+    if (e != hipSuccess) {
+        hipFree(dsrc);
+        return fail(c, OKRT_ERR_OOM, "scale_texture: hipMalloc");
+    }
+    e = hipMemcpyAsync(dsrc, src, sb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launchScaleTexture((const uint8_t*)dsrc, sw, sh, (uint8_t*)ddst, dw, dh, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, ddst, db, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dsrc);
+    hipFree(ddst);
+    if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("scale_texture: ") + hipGetErrorString(e));
+    return OKRT_OK;
+}
+
+okrt_status okrt_resize(okrt_ctx* c, uint32_t width, uint32_t height) {
+    if (!c || !width || !height || width > 65536 || height > 65536) return fail(c, OKRT_ERR_INVALID_ARG, "resize: bad dimensions");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    c->W = width;
+    c->H = height;
+    c->tile = TileView{width, height, height, height, 0, 1};
+    return allocFramebuffers(c);
+}
+
+okrt_status okrt_set_tile(okrt_ctx* c, uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_stride) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    if (!c->W) return fail(c, OKRT_ERR_STATE, "set_tile before resize");
+    if (!stripe_rows || !stripe_stride || stripe_index >= stripe_stride) return fail(c, OKRT_ERR_INVALID_ARG, "set_tile: bad stripe");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    c->tile = TileView{c->W, c->H, ownedRows(c->H, stripe_rows, stripe_index, stripe_stride), stripe_rows, stripe_index, stripe_stride};
+    return allocFramebuffers(c);
+}
+
+okrt_status okrt_tile_rows(const okrt_ctx* c, uint32_t* out) {
+    if (!c || !out) return OKRT_ERR_INVALID_ARG;
+    *out = c->tile.rows;
+    return OKRT_OK;
+}
+
+okrt_status okrt_bind_framebuffers(okrt_ctx* c, void* accum_dev, void* result_dev) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    if (!c->W) return fail(c, OKRT_ERR_STATE, "bind_framebuffers before resize");
+    c->accum = accum_dev ? (float4*)accum_dev : (float4*)c->accumOwn.ptr;
+    c->result = result_dev ? (uint32_t*)result_dev : (uint32_t*)c->resultOwn.ptr;
+    return OKRT_OK;
+}
+
+okrt_status okrt_reset_accumulation(okrt_ctx* c) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    if (!c->accum) return OKRT_OK;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->tile.rows * c->W * sizeof(float4), c->stream));
+    return OKRT_OK;
+}
+
+okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
+    if (!c || !rd) return OKRT_ERR_INVALID_ARG;
+    if (!c->W) return fail(c, OKRT_ERR_STATE, "render before resize");
+    if (rd->textureDims[0] != c->W || rd->textureDims[1] != c->H) return fail(c, OKRT_ERR_INVALID_ARG, "render: textureDims differ from the resize dimensions");
+    if (rd->numSpheres > c->tables[OKRT_TABLE_SPHERE].count || rd->numDirLights > c->tables[OKRT_TABLE_DIR_LIGHT].count ||
+        rd->numPointLights > c->tables[OKRT_TABLE_POINT_LIGHT].count || rd->numSpotLights > c->tables[OKRT_TABLE_SPOT_LIGHT].count)
+        return fail(c, OKRT_ERR_RANGE, "render: a count in RenderData exceeds its uploaded table");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    if (c->tablesDirty) {
+        okrt_status s = validateTables(c);
+        c->tablesValid = s == OKRT_OK;
+        c->tablesDirty = false;
+        if (s != OKRT_OK) return s;
+    }
+    if (!c->tablesValid) return fail(c, OKRT_ERR_RANGE, "render: the uploaded tables failed validation");
+    if (!c->tile.rows) return OKRT_OK;
+
+    SceneView view = makeView(c);
+    unsigned long long* counters = c->countersOn ? (unsigned long long*)c->counters.ptr : nullptr;
+    if (c->timingOn) OKRT_HIP(c, hipEventRecord(c->evR0, c->stream));
+    if (c->traversal == OKRT_TRAVERSAL_REFERENCE) {
+        launchReferenceOrder(view, *rd, c->tile, c->accum, c->result, counters, c->stream);
+    } else {
+        if (c->fastDirty) {
+            std::string msg;
+            FastInputs in;
+            in.triPos = (const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].host.data();
+            in.numTris = c->tables[OKRT_TABLE_TRI_POS].count;
+            in.bvh = (const BvhNodeRec*)c->tables[OKRT_TABLE_BVH].host.data();
+            in.numNodes = c->tables[OKRT_TABLE_BVH].count;
+            in.oct = (const OctNodeRec*)c->tables[OKRT_TABLE_OCT].host.data();
+            in.numOct = c->tables[OKRT_TABLE_OCT].count;
+            in.meshes = (const MeshRec*)c->tables[OKRT_TABLE_MESH].host.data();
+            in.numMeshes = c->tables[OKRT_TABLE_MESH].count;
+            OKRT_HIP(c, hipStreamSynchronize(c->stream));
+            if (!fastBuild(&c->fast, in, c->stream, msg)) return fail(c, OKRT_ERR_DEVICE, "fast structure: " + msg);
+            c->fastDirty = false;
+        }
+        launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, c->stream);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (c->timingOn) OKRT_HIP(c, hipEventRecord(c->evR1, c->stream));
+    c->lastRenderTimed = c->timingOn;
+    return OKRT_OK;
+}
+
+okrt_status okrt_synchronize(okrt_ctx* c) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    return OKRT_OK;
+}
+
+okrt_status okrt_read_result_rgba8(okrt_ctx* c, uint8_t* dst) {
+    if (!c || !dst) return OKRT_ERR_INVALID_ARG;
+    if (!c->result) return fail(c, OKRT_ERR_STATE, "read before resize");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipMemcpyAsync(dst, c->result, (size_t)c->tile.rows * c->W * 4, hipMemcpyDeviceToHost, c->stream));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    return OKRT_OK;
+}
+
+okrt_status okrt_read_accum_f32x4(okrt_ctx* c, float* dst) {
+    if (!c || !dst) return OKRT_ERR_INVALID_ARG;
+    if (!c->accum) return fail(c, OKRT_ERR_STATE, "read before resize");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipMemcpyAsync(dst, c->accum, (size_t)c->tile.rows * c->W * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    return OKRT_OK;
+}
+
+okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    switch (opt) {
+        case OKRT_OPT_TRAVERSAL:
+            if (value != OKRT_TRAVERSAL_REFERENCE && value != OKRT_TRAVERSAL_FAST) return fail(c, OKRT_ERR_INVALID_ARG, "traversal: 0 or 1");
+            c->traversal = (int)value;
+            return OKRT_OK;
+        case OKRT_OPT_MAX_BOUNCES:
+            if (value < 0 || value > 64) return fail(c, OKRT_ERR_INVALID_ARG, "max_bounces: 0..64");
+            c->maxBounces = (int)value;
+            return OKRT_OK;
+        case OKRT_OPT_COUNTERS: c->countersOn = value != 0; return OKRT_OK;
+        case OKRT_OPT_TIMING: c->timingOn = value != 0; return OKRT_OK;
+        default: return fail(c, OKRT_ERR_INVALID_ARG, "unknown option");
+    }
+}
+
+okrt_status okrt_get_counters(okrt_ctx* c, okrt_counters* out) {
+    if (!c || !out) return OKRT_ERR_INVALID_ARG;
+    static_assert(sizeof(okrt_counters) == kNumCounters * sizeof(uint64_t), "counter layout");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipMemcpyAsync(out, c->counters.ptr, sizeof(okrt_counters), hipMemcpyDeviceToHost, c->stream));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    return OKRT_OK;
+}
+
+okrt_status okrt_reset_counters(okrt_ctx* c) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipMemsetAsync(c->counters.ptr, 0, c->counters.bytes, c->stream));
+    return OKRT_OK;
+}
+
+okrt_status okrt_set_stream(okrt_ctx* c, void* hip_stream) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
+    return OKRT_OK;
+}
+
+okrt_status okrt_timer_begin(okrt_ctx* c) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipEventRecord(c->evBegin, c->stream));
+    return OKRT_OK;
+}
+okrt_status okrt_timer_end(okrt_ctx* c) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipEventRecord(c->evEnd, c->stream));
+    return OKRT_OK;
+}
+okrt_status okrt_timer_elapsed_ms(okrt_ctx* c, float* out_ms) {
+    if (!c || !out_ms) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipEventSynchronize(c->evEnd));
+    OKRT_HIP(c, hipEventElapsedTime(out_ms, c->evBegin, c->evEnd));
+    return OKRT_OK;
+}
+okrt_status okrt_last_render_ms(okrt_ctx* c, float* out_ms) {
+    if (!c || !out_ms) return OKRT_ERR_INVALID_ARG;
+    if (!c->lastRenderTimed) return fail(c, OKRT_ERR_STATE, "last_render_ms: enable OKRT_OPT_TIMING before rendering");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipEventSynchronize(c->evR1));
+    OKRT_HIP(c, hipEventElapsedTime(out_ms, c->evR0, c->evR1));
+    return OKRT_OK;
+}
+
+const okrt_api* okrt_get_api(void) {
+    static const okrt_api api = {OKRT_ABI_VERSION,     okrt_create,        okrt_destroy,      okrt_last_error,
+                                 okrt_set_table,       okrt_set_textures,  okrt_set_envmap,   okrt_scale_texture_rgba8,
+                                 okrt_resize,          okrt_set_tile,      okrt_tile_rows,    okrt_reset_accumulation,
+                                 okrt_render,          okrt_synchronize,   okrt_read_result_rgba8, okrt_read_accum_f32x4,
+                                 okrt_set_option,      okrt_get_counters,  okrt_reset_counters};
+    return &api;
+}
+
+}  // extern "C"

@@ -1,0 +1,26 @@
+// okrt_kernels.h — launch interface between the context (okrt_context.hip) and the kernels.
+#pragma once
+#include "okrt_device.h"
+
+namespace okrt {
+
+// The rows this context owns (okrt_set_tile): local row l <-> global y.
+struct TileView {
+    uint32_t W, H;        // full frame
+    uint32_t rows;        // owned rows
+    uint32_t stripeRows, stripeIndex, stripeStride;
+    __host__ __device__ uint32_t globalRow(uint32_t l) const {
+        return ((l / stripeRows) * stripeStride + stripeIndex) * stripeRows + (l % stripeRows);
+    }
+};
+
+constexpr int kNumCounters = 12;  // layout of okrt_counters
+
+// Reference-order megakernel (okrt_ref_kernel.hip).
+void launchReferenceOrder(const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
+                          unsigned long long* counters, hipStream_t stream);
+
+// One bilinear tap per output texel (okrt_ref_kernel.hip).
+void launchScaleTexture(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, hipStream_t stream);
+
+}  // namespace okrt

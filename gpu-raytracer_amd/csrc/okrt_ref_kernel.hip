@@ -1,0 +1,180 @@
+// okrt_ref_kernel.hip — the reference-ORDER path-tracing kernel for gfx950.
+//
+// One thread per pixel, the whole path in one launch, traversing the uploaded tables exactly as the
+// reference's compute shader does (RaytracerCS.hlsl:218-334): spheres, then the octree stack, the
+// instances of each octree node, each instance's BVH with the right child popped first, every
+// triangle of a leaf. Its purpose is parity and accounting, not speed: visit order, tie-breaking
+// and the bbCheckCount / triCheckCount debug counters are those of the reference, which makes its
+// counters the layout-independent "algorithmic bytes" numerator of the roofline.
+// The fast traversal (okrt_fast_kernel.hip) is checked against this kernel and the CPU oracle.
+//
+// Launch shape: 256-thread blocks = 4 wave64, each wave an 8x8 pixel tile (the reference's 16x9
+// groups are 2.25 waves; quirk Q16), blocks cover 16x16 pixels; every pixel of the owned rows is
+// rendered (the reference truncates to multiples of 16x9; quirk Q15).
+#include "okrt_kernels.h"
+
+namespace okrt {
+
+namespace {
+
+constexpr uint32_t kOctStack = 20;  // RaytracerCS.hlsl:244
+constexpr uint32_t kBvhStack = 50;  // RaytracerCS.hlsl:249
+
+OKRT_DEV Hit closestHitReferenceOrder(const SceneView& s, const okrt_render_data& rd, const Ray& ray, uint32_t& bbCheckCount,
+                                      uint32_t& triCheckCount, PathCounters& cnt) {
+    Hit h;
+    h.distance = kFltMax;
+    h.hitIdx = kInvalid;
+    h.hitType = 0;
+    h.triIdx = kInvalid;
+    h.bu = h.bv = 0.f;
+    cnt.segments++;
+
+    for (uint32_t i = 0; i < rd.numSpheres; i++) {  // :232-242
+        float d = rayAndSphere(ray, ld3(s.spheres[i].position), s.spheres[i].radius);
+        if (d > 0.f && d < h.distance) {
+            h.distance = d;
+            h.hitIdx = i;
+            h.hitType = 0;
+        }
+    }
+
+    uint32_t octStack[kOctStack];
+    uint32_t octStackSize = 0;
+    if (s.numOct) octStack[octStackSize++] = 0;
+    uint32_t bvhStack[kBvhStack];
+    const V3 invDirWorld = rcp3(ray.direction);
+
+    while (octStackSize > 0) {  // :256-334
+        const OctNodeRec& on = s.oct[octStack[--octStackSize]];
+        bbCheckCount += 1;
+        cnt.nOct++;
+        if (rayAndAABBDist(ray.origin, invDirWorld, ld3(on.bbMin), ld3(on.bbMax)) >= h.distance) continue;
+
+        const uint32_t mEnd = on.meshesEnd;
+        for (uint32_t i = on.meshesStart; i < mEnd; i++) {  // :265-328
+            bbCheckCount += 1;
+            cnt.nMesh++;
+            const MeshRec& mesh = s.meshes[i];
+            uint32_t bvhStackSize = 1;
+            bvhStack[0] = mesh.bvhNodeStartIdx;
+            const V3 lo = matPoint(mesh.Minv, ray.origin);
+            const V3 ld = normalize(matDir(mesh.Minv, ray.direction));
+            const V3 linv = rcp3(ld);
+
+            while (bvhStackSize > 0) {  // :278-327
+                const BvhNodeRec& node = s.bvh[bvhStack[--bvhStackSize]];
+                bbCheckCount += 1;
+                cnt.nNode++;
+                if (rayAndAABBDist(lo, linv, ld3(node.bbMin), ld3(node.bbMax)) >= h.distance) continue;
+                const uint32_t first = node.firstChild;
+                if (first != kInvalid) {
+                    if (bvhStackSize + 2 <= kBvhStack) {
+                        bvhStack[bvhStackSize++] = first;
+                        bvhStack[bvhStackSize++] = first + 1;
+                    }
+                    continue;
+                }
+                const uint32_t tEnd = node.triEnd;
+                for (uint32_t j = node.triStart; j < tEnd; j++) {  // :295-326
+                    const float* p = s.triPos[j].p;
+                    V3 p2 = ld3(p + 6);
+                    float bu = 0.f, bv = 0.f;
+                    triCheckCount += 1;
+                    cnt.nTri++;
+                    float d = rayAndTriangleEdges(lo, ld, p2, ld3(p) - p2, ld3(p + 3) - p2, bu, bv);
+                    if (d <= 0.f) continue;
+                    d = length(matDir(mesh.M, ld * d));  // world-space distance (:311-314)
+                    if (d < h.distance) {
+                        h.distance = d;
+                        h.hitIdx = i;
+                        h.hitType = 1;
+                        h.triIdx = j;
+                        h.bu = bu;
+                        h.bv = bv;
+                    }
+                }
+            }
+        }
+        for (uint32_t i = 0; i < on.numChildren; i++)  // :330-333
+            if (octStackSize < kOctStack) octStack[octStackSize++] = on.firstChild + i;
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(256) void renderReferenceOrder(SceneView s, okrt_render_data rd, TileView tile, float4* accum,
+                                                           uint32_t* result, unsigned long long* counters) {
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const uint32_t lrow = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool active = px < tile.W && lrow < tile.rows;
+
+    PathCounters cnt = {};
+    if (active) {
+        const uint32_t py = tile.globalRow(lrow);
+        uint32_t seed;
+        Ray ray = primaryRay(rd, px, py, seed);
+        V3 light = mk(0.f, 0.f, 0.f), contribution = mk(1.f, 1.f, 1.f);
+        uint32_t bb = 0, tri = 0;
+        for (uint32_t i = 0; i <= s.maxBounces; i++) {  // RaytracerCS.hlsl:444-514
+            Hit h = closestHitReferenceOrder(s, rd, ray, bb, tri, cnt);
+            Surface sf = shadeFetch(s, ray, h, cnt);
+            addLights(s, rd, ray, sf, i, contribution, light, seed);
+            if (!sf.hit) {
+                light = fma3(sampleEnvironment(s, ray.direction, cnt), contribution, light);
+                break;
+            }
+            scatter(sf, ray, contribution, light, seed);
+        }
+        writePixel(rd, light, bb, tri, accum, result, (size_t)lrow * tile.W + px);
+    }
+
+    if (counters) {  // wave-level sums, one atomic per counter per wave
+        uint32_t vals[kNumCounters] = {active ? 1u : 0u, cnt.segments, cnt.nOct, cnt.nMesh, cnt.nNode, cnt.nTri,
+                                       cnt.meshHits, cnt.sphereHits, cnt.texTaps, cnt.envTaps, cnt.fastNodes, cnt.fastTris};
+#pragma unroll
+        for (int k = 0; k < kNumCounters; ++k) {
+            uint32_t v = vals[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&counters[k], (unsigned long long)v);
+        }
+    }
+}
+
+// Okay::scaleTexture (DX11.cpp:232-268 + Scale/ScalePS.hlsl): one bilinear tap at the output texel
+// centre, default sampler after ClearState (LINEAR, CLAMP), RGBA8 UNORM render target.
+__global__ __launch_bounds__(256) void scaleTextureKernel(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh) {
+    const uint32_t ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= dw || oy >= dh) return;
+    float u = ((float)ox + 0.5f) / (float)dw, v = ((float)oy + 0.5f) / (float)dh;
+    float x = fma_(u, (float)sw, -0.5f), y = fma_(v, (float)sh, -0.5f);
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = min(max((int)fx0, 0), (int)sw - 1), x1 = min(max((int)fx0 + 1, 0), (int)sw - 1);
+    int y0 = min(max((int)fy0, 0), (int)sh - 1), y1 = min(max((int)fy0 + 1, 0), (int)sh - 1);
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t c00 = s32[(size_t)y0 * sw + x0], c10 = s32[(size_t)y0 * sw + x1], c01 = s32[(size_t)y1 * sw + x0], c11 = s32[(size_t)y1 * sw + x1];
+    uint32_t out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        float t00 = (float)((c00 >> (8 * ch)) & 255u) / 255.f, t10 = (float)((c10 >> (8 * ch)) & 255u) / 255.f;
+        float t01 = (float)((c01 >> (8 * ch)) & 255u) / 255.f, t11 = (float)((c11 >> (8 * ch)) & 255u) / 255.f;
+        out |= toUnorm8(lerp(lerp(t00, t10, fx), lerp(t01, t11, fx), fy)) << (8 * ch);
+    }
+    reinterpret_cast<uint32_t*>(dst)[(size_t)oy * dw + ox] = out;
+}
+
+}  // namespace
+
+void launchReferenceOrder(const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
+                          unsigned long long* counters, hipStream_t stream) {
+    dim3 grid((t.W + 15) / 16, (t.rows + 15) / 16);
+    hipLaunchKernelGGL(renderReferenceOrder, grid, dim3(256), 0, stream, s, rd, t, accum, result, counters);
+}
+
+void launchScaleTexture(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, hipStream_t stream) {
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(scaleTextureKernel, grid, dim3(256), 0, stream, src, sw, sh, dst, dw, dh);
+}
+
+}  // namespace okrt

@@ -1,0 +1,242 @@
+/*
+ * okrt.h — C ABI of the MI355X path-tracing core ("okrt" = Okay ray tracer device layer).
+ *
+ * This is the drop-in boundary: everything the reference's `RayTracer` host class asks of its
+ * DirectX11 device layer for the compute path, restated as plain C entry points over HIP.
+ * All `file:line` citations are relative to the reference checkout (Olowerr/GPU-Raytracer).
+ *
+ *   reference call                                           ->  okrt entry point
+ *   -------------------------------------------------------------------------------------------
+ *   Okay::initiateDX11              source/DirectX/DX11.cpp:21-42      okrt_create
+ *   Okay::shutdownDX11 / RayTracer::shutdown  RayTracer.cpp:34-58      okrt_destroy
+ *   Okay::createStructuredBuffer    DX11.h:24, DX11.cpp:104-130        okrt_set_table
+ *   GPUStorage::initiate/update/updateRaw  GPUStorage.h:13-17,34-47    okrt_set_table
+ *   Okay::createTextureArray        DX11.h:36, DX11.cpp:270-313        okrt_set_textures
+ *   Okay::scaleTexture              DX11.h:34, DX11.cpp:232-268        okrt_scale_texture_rgba8
+ *   cube-map creation               RayTracer.cpp:403-431              okrt_set_envmap
+ *   RenderTexture::initiate/resize  RenderTexture.h:44-57, RayTracer.cpp:73,494-501   okrt_resize
+ *   ClearUnorderedAccessViewFloat(accum)  RayTracer.h:203-209          okrt_reset_accumulation
+ *   Okay::updateBuffer(RenderData) + Dispatch  RayTracer.cpp:491,219-260   okrt_render
+ *   Okay::getCPUTextureData         DX11.h:32, DX11.cpp:196-230        okrt_read_result_rgba8
+ *   (no reference counterpart: float accumulation readback)            okrt_read_accum_f32x4
+ *   Okay::createShader/reloadShader DX11.h:18-22                       (nothing: kernels are AOT)
+ *
+ * Conventions
+ *   - Every call returns an `okrt_status` (0 = OK, negative = error); nothing aborts. The
+ *     message of the last failure is available from okrt_last_error(). (The reference returns
+ *     `bool` wrapped in OKAY_ASSERT, Utilities.h:9-13.)
+ *   - The caller owns every host pointer; the library copies during the call (D3D11 copies
+ *     pSysMem at create time, DX11.cpp:113-118). The library owns device memory.
+ *   - A context is not thread-safe; one context per GPU; calls are ordered on one HIP stream;
+ *     the read_* calls synchronise. (The reference has one immediate context, DX11.cpp:12-19.)
+ *   - Table byte layouts are exactly the reference's structured-buffer layouts
+ *     (resources/shaders/GPU-Structs.hlsli:7-179); element sizes are checked.
+ *   - No torch / C++ types cross this boundary: plain pointers and sizes only.
+ */
+#ifndef OKRT_H
+#define OKRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OKRT_ABI_VERSION 1
+
+typedef struct okrt_ctx okrt_ctx;
+
+typedef enum okrt_status {
+    OKRT_OK = 0,
+    OKRT_ERR_INVALID_ARG = -1, /* bad pointer / size / enum / element stride */
+    OKRT_ERR_DEVICE = -2,      /* a HIP runtime call failed (message has the HIP error) */
+    OKRT_ERR_OOM = -3,         /* allocation failed */
+    OKRT_ERR_STATE = -4,       /* call order: e.g. render before resize */
+    OKRT_ERR_RANGE = -5        /* a table index points outside its table (validated at commit) */
+} okrt_status;
+
+/* Table slots are numbered like the reference's t-registers
+ * (resources/shaders/ShaderResourceRegisters.h:9-21,34-46). Slots 3 (textures) and 4
+ * (environment map) are images and have their own setters. */
+typedef enum okrt_table {
+    OKRT_TABLE_TRI_POS = 0,   /* t0  Triangle          36 B  GPU-Structs.hlsli:95-98   */
+    OKRT_TABLE_TRI_INFO = 1,  /* t1  TriangleInfo     132 B  GPU-Structs.hlsli:100-111 */
+    OKRT_TABLE_BVH = 2,       /* t2  BvhNode           36 B  GPU-Structs.hlsli:159-165 */
+    OKRT_TABLE_OCT = 5,       /* t5  OctTreeNode       48 B  GPU-Structs.hlsli:167-179 */
+    OKRT_TABLE_SPHERE = 6,    /* t6  Sphere            84 B  GPU-Structs.hlsli:86-93   */
+    OKRT_TABLE_MESH = 7,      /* t7  Mesh             232 B  GPU-Structs.hlsli:113-125 */
+    OKRT_TABLE_DIR_LIGHT = 8, /* t8  DirectionalLight  32 B  GPU-Structs.hlsli:127-135 */
+    OKRT_TABLE_POINT_LIGHT = 9, /* t9  PointLight      32 B  GPU-Structs.hlsli:137-145 */
+    OKRT_TABLE_SPOT_LIGHT = 10  /* t10 SpotLight       48 B  GPU-Structs.hlsli:147-157 */
+} okrt_table;
+
+#define OKRT_SIZEOF_TRIANGLE 36u
+#define OKRT_SIZEOF_TRIANGLE_INFO 132u
+#define OKRT_SIZEOF_BVH_NODE 36u
+#define OKRT_SIZEOF_OCT_NODE 48u
+#define OKRT_SIZEOF_SPHERE 84u
+#define OKRT_SIZEOF_MESH 232u
+#define OKRT_SIZEOF_DIR_LIGHT 32u
+#define OKRT_SIZEOF_POINT_LIGHT 32u
+#define OKRT_SIZEOF_SPOT_LIGHT 48u
+#define OKRT_SIZEOF_MATERIAL 68u
+#define OKRT_SIZEOF_RENDER_DATA 240u
+
+/* The b0 constant buffer, byte for byte (resources/shaders/RaytracerCS.hlsl:19-47, host mirror
+ * source/Graphics/RayTracer.h:129-157). Matrices are what the host uploads:
+ * glm::transpose(glm::inverse(M)) in glm's column-major memory order (RayTracer.cpp:295-296,
+ * 306-307), i.e. the 16 floats are inverse(M) in row-major order. */
+typedef struct okrt_render_data {
+    uint32_t accumulationEnabled;   /*   0 */
+    uint32_t numAccumulationFrames; /*   4  already incremented by the host (RayTracer.cpp:489) */
+    uint32_t numSpheres;            /*   8 */
+    uint32_t numMeshes;             /*  12  unused by the kernel */
+    uint32_t numDirLights;          /*  16 */
+    uint32_t numPointLights;        /*  20 */
+    uint32_t numSpotLights;         /*  24 */
+    uint32_t debugMode;             /*  28  0 none, 1 bbCheckCount, 2 triCheckCount (RayTracer.h:74-79) */
+    uint32_t textureDims[2];        /*  32  FULL-frame W,H (also when rendering a tile) */
+    float viewPlaneDims[2];         /*  40  unused by the live code path */
+    float cameraInverseProjectionMatrix[16]; /*  48 */
+    float cameraInverseViewMatrix[16];       /* 112 */
+    float cameraPosition[3];        /* 176 */
+    float cameraNearZ;              /* 188 */
+    float cameraUpDir[3];           /* 192 */
+    float dofStrength;              /* 204 */
+    float cameraRightDir[3];        /* 208 */
+    float dofDistance;              /* 220 */
+    uint32_t debugMaxCount;         /* 224 */
+    float pad0[3];                  /* 228 */
+} okrt_render_data;
+
+/* Options (okrt_set_option). */
+typedef enum okrt_option {
+    /* 0 = reference-order traversal over the uploaded octree -> mesh -> BVH tables
+     *     (RaytracerCS.hlsl:256-334, bit-identical visit order; produces the reference's
+     *     bbCheckCount / triCheckCount);
+     * 1 = (default) the MI355X traversal structure derived from the same tables at commit. */
+    OKRT_OPT_TRAVERSAL = 0,
+    /* NUM_BOUNCES of RaytracerCS.hlsl:6 (default 1 = HEAD; a path has max_bounces+1 segments). */
+    OKRT_OPT_MAX_BOUNCES = 1,
+    /* 1 = sum the traversal counters of every render into okrt_counters (default 0). */
+    OKRT_OPT_COUNTERS = 2,
+    /* 1 = record HIP events around every render's kernels so okrt_last_render_ms works. */
+    OKRT_OPT_TIMING = 3
+} okrt_option;
+
+#define OKRT_TRAVERSAL_REFERENCE 0
+#define OKRT_TRAVERSAL_FAST 1
+
+/* Sums over all rendered pixels since the last okrt_reset_counters. The first five are defined
+ * by the reference traversal order (they are what the reference's debug heat maps count,
+ * RaytracerCS.hlsl:261,267,284,305) and are only filled in OKRT_TRAVERSAL_REFERENCE mode. */
+typedef struct okrt_counters {
+    uint64_t pixels;     /* samples started */
+    uint64_t segments;   /* findClosestHit invocations = rays traced */
+    uint64_t n_oct;      /* octree nodes popped        (RaytracerCS.hlsl:258-261) */
+    uint64_t n_mesh;     /* instances entered          (RaytracerCS.hlsl:265-272) */
+    uint64_t n_node;     /* BVH nodes popped           (RaytracerCS.hlsl:280-284) */
+    uint64_t n_tri;      /* triangles tested           (RaytracerCS.hlsl:297-306) */
+    uint64_t mesh_hits;  /* segments whose closest hit is a mesh triangle (TriangleInfo fetch) */
+    uint64_t sphere_hits;
+    uint64_t tex_taps;   /* bilinear material/normal-map taps */
+    uint64_t env_taps;   /* environment lookups on a miss */
+    uint64_t fast_nodes; /* OKRT_TRAVERSAL_FAST: wide-node visits (diagnostic) */
+    uint64_t fast_tris;  /* OKRT_TRAVERSAL_FAST: triangle tests (diagnostic) */
+} okrt_counters;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int okrt_abi_version(void);
+okrt_status okrt_create(int device, okrt_ctx** out_ctx);
+okrt_status okrt_destroy(okrt_ctx* ctx);
+const char* okrt_last_error(const okrt_ctx* ctx); /* never NULL; "" when no error */
+
+/* ---- scene upload (the Scene->Graphics interface) ------------------------------------------ */
+/* Replace a whole table. `elem_bytes` must equal the slot's reference stride. count==0 or
+ * data==NULL empties the table. A different count reallocates (GPUStorage.h:36-37). */
+okrt_status okrt_set_table(okrt_ctx* ctx, okrt_table slot, const void* data,
+                           uint32_t elem_bytes, uint32_t count);
+/* Texture2DArray of `count` RGBA8 slices of width x height (linear, no sRGB: DX11.cpp:281). */
+okrt_status okrt_set_textures(okrt_ctx* ctx, const uint8_t* rgba8, uint32_t count,
+                              uint32_t width, uint32_t height);
+/* TextureCube: 6 RGBA8 faces of face x face in D3D order +X,-X,+Y,-Y,+Z,-Z
+ * (RayTracer.cpp:377-399). NULL / face==0 unbinds it (environment reads black). */
+okrt_status okrt_set_envmap(okrt_ctx* ctx, const uint8_t* rgba8_6faces, uint32_t face);
+/* One bilinear tap per output texel, CLAMP addressing, RGBA8 out (DX11.cpp:232-268 with
+ * resources/shaders/Scale/ScalePS.hlsl). src/dst are host pointers. */
+okrt_status okrt_scale_texture_rgba8(okrt_ctx* ctx, const uint8_t* src, uint32_t src_w,
+                                     uint32_t src_h, uint8_t* dst, uint32_t dst_w, uint32_t dst_h);
+
+/* ---- framebuffer --------------------------------------------------------------------------- */
+/* (Re)allocate result (RGBA8) + accumulation (float4) for a W x H frame and zero the
+ * accumulation (RayTracer::onResize, RayTracer.cpp:494-501). Resets the tile to the full frame. */
+okrt_status okrt_resize(okrt_ctx* ctx, uint32_t width, uint32_t height);
+/* Image-space split for multi-GPU (new; the reference is single-GPU). The frame is cut into
+ * horizontal stripes of `stripe_rows` rows; this context owns stripes
+ * stripe_index, stripe_index+stripe_stride, ... Its framebuffers hold only the owned rows,
+ * packed in order. Seeds use GLOBAL pixel coordinates, so owned pixels are bit-identical to a
+ * full-frame render (RaytracerCS.hlsl:430). (H,0,1) = full frame. Zeroes the accumulation. */
+okrt_status okrt_set_tile(okrt_ctx* ctx, uint32_t stripe_rows, uint32_t stripe_index,
+                          uint32_t stripe_stride);
+/* Number of rows this context owns under the current tile. */
+okrt_status okrt_tile_rows(const okrt_ctx* ctx, uint32_t* out_rows);
+/* Render into caller-owned device memory instead (e.g. a torch tensor used by an RCCL gather).
+ * accum_dev: rows*W float4, result_dev: rows*W RGBA8; NULL selects the internal buffer.
+ * Must be re-bound after okrt_resize / okrt_set_tile. */
+okrt_status okrt_bind_framebuffers(okrt_ctx* ctx, void* accum_dev, void* result_dev);
+okrt_status okrt_reset_accumulation(okrt_ctx* ctx);
+
+/* ---- render + readback --------------------------------------------------------------------- */
+/* One frame = one sample per owned pixel; asynchronous on the context's stream. */
+okrt_status okrt_render(okrt_ctx* ctx, const okrt_render_data* rd);
+okrt_status okrt_synchronize(okrt_ctx* ctx);
+/* Owned rows only, packed: rows*W*4 bytes / rows*W*4 floats. Row 0 = top of the image. */
+okrt_status okrt_read_result_rgba8(okrt_ctx* ctx, uint8_t* dst);
+okrt_status okrt_read_accum_f32x4(okrt_ctx* ctx, float* dst);
+
+/* ---- options, counters, timing ------------------------------------------------------------- */
+okrt_status okrt_set_option(okrt_ctx* ctx, okrt_option opt, int64_t value);
+okrt_status okrt_get_counters(okrt_ctx* ctx, okrt_counters* out); /* synchronises */
+okrt_status okrt_reset_counters(okrt_ctx* ctx);
+/* Use a caller-provided hipStream_t (NULL restores the context's own stream). */
+okrt_status okrt_set_stream(okrt_ctx* ctx, void* hip_stream);
+/* HIP-event timing on the context's stream: begin/end bracket any number of okrt_render calls;
+ * okrt_timer_elapsed_ms synchronises on the end event. */
+okrt_status okrt_timer_begin(okrt_ctx* ctx);
+okrt_status okrt_timer_end(okrt_ctx* ctx);
+okrt_status okrt_timer_elapsed_ms(okrt_ctx* ctx, float* out_ms);
+/* With OKRT_OPT_TIMING: device time of the kernels of the most recent okrt_render. */
+okrt_status okrt_last_render_ms(okrt_ctx* ctx, float* out_ms);
+
+/* ---- entry-point table -------------------------------------------------------------------------
+ * The same entry points as a struct of function pointers, so a host written against this ABI
+ * (gpu-raytracer_amd/host: the mirror of the reference's RayTracer class) binds to the device
+ * layer at run time instead of at link time. okrt_get_api() returns the HIP implementation. */
+typedef struct okrt_api {
+    uint32_t abi_version;
+    okrt_status (*create)(int device, okrt_ctx** out_ctx);
+    okrt_status (*destroy)(okrt_ctx* ctx);
+    const char* (*last_error)(const okrt_ctx* ctx);
+    okrt_status (*set_table)(okrt_ctx*, okrt_table, const void*, uint32_t, uint32_t);
+    okrt_status (*set_textures)(okrt_ctx*, const uint8_t*, uint32_t, uint32_t, uint32_t);
+    okrt_status (*set_envmap)(okrt_ctx*, const uint8_t*, uint32_t);
+    okrt_status (*scale_texture_rgba8)(okrt_ctx*, const uint8_t*, uint32_t, uint32_t, uint8_t*, uint32_t, uint32_t);
+    okrt_status (*resize)(okrt_ctx*, uint32_t, uint32_t);
+    okrt_status (*set_tile)(okrt_ctx*, uint32_t, uint32_t, uint32_t);
+    okrt_status (*tile_rows)(const okrt_ctx*, uint32_t*);
+    okrt_status (*reset_accumulation)(okrt_ctx*);
+    okrt_status (*render)(okrt_ctx*, const okrt_render_data*);
+    okrt_status (*synchronize)(okrt_ctx*);
+    okrt_status (*read_result_rgba8)(okrt_ctx*, uint8_t*);
+    okrt_status (*read_accum_f32x4)(okrt_ctx*, float*);
+    okrt_status (*set_option)(okrt_ctx*, okrt_option, int64_t);
+    okrt_status (*get_counters)(okrt_ctx*, okrt_counters*);
+    okrt_status (*reset_counters)(okrt_ctx*);
+} okrt_api;
+
+const okrt_api* okrt_get_api(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKRT_H */
