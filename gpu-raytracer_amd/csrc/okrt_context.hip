@@ -368,7 +368,9 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
     SceneView view = makeView(c);
     unsigned long long* counters = c->countersOn ? (unsigned long long*)c->counters.ptr : nullptr;
     if (c->timingOn) OKRT_HIP(c, hipEventRecord(c->evR0, c->stream));
-    if (c->traversal == OKRT_TRAVERSAL_REFERENCE) {
+    // The debug heat maps count the REFERENCE traversal's box/triangle checks (RaytracerCS.hlsl:516-520),
+    // so those frames always run the reference-order kernel.
+    if (c->traversal == OKRT_TRAVERSAL_REFERENCE || rd->debugMode != 0) {
         launchReferenceOrder(view, *rd, c->tile, c->accum, c->result, counters, c->stream);
     } else {
         if (c->fastDirty) {
@@ -386,7 +388,8 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
             if (!fastBuild(&c->fast, in, c->stream, msg)) return fail(c, OKRT_ERR_DEVICE, "fast structure: " + msg);
             c->fastDirty = false;
         }
-        launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, c->stream);
+        std::string msg;
+        if (!launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, c->stream, msg)) return fail(c, OKRT_ERR_OOM, "fast pipeline: " + msg);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -1,10 +1,43 @@
-// okrt_fast.h — interface of the MI355X traversal structure (okrt_fast_build.cpp, okrt_fast_kernel.hip).
+// okrt_fast.h — the MI355X traversal structure derived from the uploaded reference tables, and
+// the wavefront pipeline that traces it (okrt_fast_build.cpp, okrt_fast_kernel.hip).
+//
+// Layout in HBM (all 16-byte aligned, 128-byte node stride = one L2 line per node visit):
+//   Node4   128 B  four child boxes as SoA rows (minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4]),
+//                  child[4] references, 16 B spare. One visit = 7 x global_load_dwordx4 per lane.
+//   Tri48    48 B  p2, E1 = p0-p2, E2 = p1-p2 (the reference's Moeller-Trumbore edge convention,
+//                  GPU-Utilities.hlsli:124) + source triangle index (into t0/t1) + instance index.
+//                  One test = 3 x global_load_dwordx4.
+// Child reference: bit 31 set = leaf {count-1 : 4 bits, first triangle : 27 bits}; else node index;
+// kEmptyRef = unused slot (its box is inverted and can never be hit).
 #pragma once
 #include <string>
+#include <vector>
 
 #include "okrt_kernels.h"
 
 namespace okrt {
+
+struct alignas(16) Node4 {
+    float bmin[3][4];   // [axis][child]
+    float bmax[3][4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "Node4 is one 128-byte line");
+
+struct alignas(16) Tri48 {
+    float p2[3];
+    uint32_t srcTri;    // index into t0 / t1 (TriangleInfo fetch)
+    float e1[3];
+    uint32_t instance;  // index into t7 (material + matrix)
+    float e2[3];
+    uint32_t pad;
+};
+static_assert(sizeof(Tri48) == 48, "Tri48");
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kEmptyRef = 0xFFFFFFFFu;  // also "no more work" in the traversal loop
+constexpr uint32_t kMaxLeafTris = 15;        // 4 bits hold count-1 (15 is reserved by kEmptyRef's pattern)
 
 struct FastInputs {  // host copies of the uploaded reference tables
     const TriangleRec* triPos; uint32_t numTris;
@@ -12,11 +45,22 @@ struct FastInputs {  // host copies of the uploaded reference tables
     const OctNodeRec* oct; uint32_t numOct;
     const MeshRec* meshes; uint32_t numMeshes;
 };
-struct FastScene;  // opaque: device-resident derived structure
+
+// Host-side result of the build (okrt_fast_build.cpp); uploaded by fastBuild.
+struct FastHostScene {
+    std::vector<Node4> nodes;  // nodes[0] is the root (always present, possibly all-empty)
+    std::vector<Tri48> tris;
+    uint32_t maxDepth = 0;     // deepest leaf, in Node4 levels
+    bool allIdentity = true;   // every instance matrix is the identity (bit-exact with the reference order)
+};
+void buildFastHost(const FastInputs& in, FastHostScene& out);
+
+struct FastScene;  // device-resident structure + the wavefront queues
 
 bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std::string& err);
 void fastDestroy(FastScene* scene);
-void launchFast(const FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum,
-                uint32_t* result, unsigned long long* counters, hipStream_t stream);
+// One frame through the wavefront pipeline. Returns false (with err) if queue memory cannot be had.
+bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum,
+                uint32_t* result, unsigned long long* counters, hipStream_t stream, std::string& err);
 
 }  // namespace okrt

@@ -1,0 +1,338 @@
+// okrt_fast_build.cpp — host-side derivation of the MI355X traversal structure from the
+// reference's uploaded tables (okrt_fast.h).
+//
+// The reference traverses octree -> instance -> per-mesh BVH with no front-to-back order
+// (RaytracerCS.hlsl:256-334). The closest hit it returns is min over {triangles reachable that
+// way} of the world-space hit distance, so any structure over the same triangle set returns the
+// same hit (ties aside). Here:
+//   1. walk the octree from node 0 and collect the instances it reaches, walk each instance's BVH
+//      and collect its leaf triangles (exactly the set the shader can test);
+//   2. bake each instance's triangles into world space (identity instances bit for bit; others as
+//      M*p — quirk Q3/Q22: the reference's local-space culling is only exact for unit scale);
+//   3. build one binned-SAH BVH2 over all of them (16 bins x 3 axes, leaves <= 4 triangles),
+//      in parallel over the top subtrees;
+//   4. collapse to 4-wide nodes by repeatedly opening the child with the largest surface area and
+//      lay nodes and triangles out in depth-first order (subtrees and their leaves contiguous).
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <thread>
+#include <vector>
+
+#include "okrt_fast.h"
+
+namespace okrt {
+
+namespace {
+
+struct Box {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float* p) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], p[k]);
+            mx[k] = std::max(mx[k], p[k]);
+        }
+    }
+    void grow(const Box& b) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], b.mn[k]);
+            mx[k] = std::max(mx[k], b.mx[k]);
+        }
+    }
+    float area() const {
+        float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+        if (!(ex >= 0.f) || !(ey >= 0.f) || !(ez >= 0.f)) return 0.f;
+        return ex * ey + ey * ez + ez * ex;
+    }
+};
+
+struct Prim {
+    Box box;
+    float c[3];
+    uint32_t srcTri, instance;
+    float p[9];  // world-space p0,p1,p2
+};
+
+struct Node2 {
+    Box box;
+    int32_t left = -1, right = -1;  // children, or -1 for a leaf
+    uint32_t first = 0, count = 0;  // leaf range in the index array
+};
+
+constexpr int kBins = 16;
+constexpr uint32_t kLeafSize = 4;
+
+struct Builder {
+    std::vector<Prim>& prims;
+    std::vector<uint32_t> idx;
+    std::vector<Node2> nodes;
+    std::atomic<uint32_t> nodeCount{0};
+
+    explicit Builder(std::vector<Prim>& p) : prims(p) {
+        idx.resize(p.size());
+        for (uint32_t i = 0; i < p.size(); ++i) idx[i] = i;
+        nodes.resize(std::max<size_t>(2 * p.size(), 1));
+    }
+    uint32_t alloc() { return nodeCount.fetch_add(1); }
+
+    void build(uint32_t nodeIdx, uint32_t lo, uint32_t hi, int depth) {
+        Node2& n = nodes[nodeIdx];
+        Box bb, cb;
+        for (uint32_t i = lo; i < hi; ++i) {
+            bb.grow(prims[idx[i]].box);
+            cb.grow(prims[idx[i]].c);
+        }
+        n.box = bb;
+        uint32_t cnt = hi - lo;
+        if (cnt <= kLeafSize) {
+            n.first = lo;
+            n.count = cnt;
+            return;
+        }
+        int bestAxis = -1, bestBin = -1;
+        float bestCost = FLT_MAX;
+        for (int axis = 0; axis < 3; ++axis) {
+            float cmin = cb.mn[axis], cext = cb.mx[axis] - cb.mn[axis];
+            if (!(cext > 0.f)) continue;
+            float scale = kBins / cext;
+            Box binBox[kBins];
+            uint32_t binCnt[kBins] = {};
+            for (uint32_t i = lo; i < hi; ++i) {
+                const Prim& p = prims[idx[i]];
+                int b = std::min(kBins - 1, std::max(0, (int)((p.c[axis] - cmin) * scale)));
+                binCnt[b]++;
+                binBox[b].grow(p.box);
+            }
+            float rightArea[kBins];
+            uint32_t rightCnt[kBins];
+            Box acc;
+            uint32_t c = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                acc.grow(binBox[b]);
+                c += binCnt[b];
+                rightArea[b] = acc.area();
+                rightCnt[b] = c;
+            }
+            Box accL;
+            uint32_t cl = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                accL.grow(binBox[b]);
+                cl += binCnt[b];
+                if (!cl || !rightCnt[b + 1]) continue;
+                float cost = accL.area() * cl + rightArea[b + 1] * rightCnt[b + 1];
+                if (cost < bestCost) {
+                    bestCost = cost;
+                    bestAxis = axis;
+                    bestBin = b;
+                }
+            }
+        }
+        uint32_t mid;
+        if (bestAxis < 0) {  // all centroids coincide: split the list in half
+            mid = lo + cnt / 2;
+        } else {
+            float cmin = cb.mn[bestAxis], scale = kBins / (cb.mx[bestAxis] - cb.mn[bestAxis]);
+            auto it = std::partition(idx.begin() + lo, idx.begin() + hi, [&](uint32_t t) {
+                int b = std::min(kBins - 1, std::max(0, (int)((prims[t].c[bestAxis] - cmin) * scale)));
+                return b <= bestBin;
+            });
+            mid = (uint32_t)(it - idx.begin());
+            if (mid == lo || mid == hi) mid = lo + cnt / 2;
+        }
+        uint32_t l = alloc(), r = alloc();
+        nodes[nodeIdx].left = (int32_t)l;
+        nodes[nodeIdx].right = (int32_t)r;
+        if (depth < 4 && cnt > 20000) {  // top of a large tree: build the halves on separate threads
+            auto fut = std::async(std::launch::async, [this, l, lo, mid, depth] { build(l, lo, mid, depth + 1); });
+            build(r, mid, hi, depth + 1);
+            fut.get();
+        } else {
+            build(l, lo, mid, depth + 1);
+            build(r, mid, hi, depth + 1);
+        }
+    }
+};
+
+bool isIdentity(const float* m) {
+    static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int i = 0; i < 16; ++i)
+        if (m[i] != I[i]) return false;
+    return true;
+}
+
+struct Emitter {
+    const Builder& b;
+    FastHostScene& out;
+    uint32_t maxDepth = 0;
+
+    uint32_t emitLeaf(const Node2& n) {
+        uint32_t first = (uint32_t)out.tris.size();
+        for (uint32_t i = 0; i < n.count; ++i) {
+            const Prim& p = b.prims[b.idx[n.first + i]];
+            Tri48 t{};
+            for (int k = 0; k < 3; ++k) {
+                t.p2[k] = p.p[6 + k];
+                t.e1[k] = p.p[k] - p.p[6 + k];      // E1 = p0 - p2   (GPU-Utilities.hlsli:124)
+                t.e2[k] = p.p[3 + k] - p.p[6 + k];  // E2 = p1 - p2
+            }
+            t.srcTri = p.srcTri;
+            t.instance = p.instance;
+            out.tris.push_back(t);
+        }
+        return kLeafBit | ((n.count - 1) << 27) | first;
+    }
+
+    // Emits the Node4 for BVH2 node `root` at out.nodes[slot].
+    void emitNode(uint32_t slot, int32_t root, uint32_t depth) {
+        maxDepth = std::max(maxDepth, depth);
+        int32_t kids[4] = {b.nodes[root].left, b.nodes[root].right, -1, -1};
+        int n = 2;
+        while (n < 4) {  // open the inner child with the largest area
+            int pick = -1;
+            float best = -1.f;
+            for (int i = 0; i < n; ++i) {
+                const Node2& c = b.nodes[kids[i]];
+                if (c.left >= 0 && c.box.area() > best) {
+                    best = c.box.area();
+                    pick = i;
+                }
+            }
+            if (pick < 0) break;
+            const Node2& c = b.nodes[kids[pick]];
+            kids[pick] = c.left;
+            kids[n++] = c.right;
+        }
+        Node4 nd;
+        std::memset(&nd, 0, sizeof(nd));
+        uint32_t childSlot[4];
+        for (int i = 0; i < 4; ++i) {
+            if (i >= n) {
+                for (int k = 0; k < 3; ++k) {
+                    nd.bmin[k][i] = INFINITY;
+                    nd.bmax[k][i] = -INFINITY;
+                }
+                nd.child[i] = kEmptyRef;
+                continue;
+            }
+            const Node2& c = b.nodes[kids[i]];
+            for (int k = 0; k < 3; ++k) {
+                nd.bmin[k][i] = c.box.mn[k];
+                nd.bmax[k][i] = c.box.mx[k];
+            }
+            if (c.left < 0) {
+                nd.child[i] = emitLeaf(c);
+                maxDepth = std::max(maxDepth, depth + 1);
+            } else {
+                childSlot[i] = (uint32_t)out.nodes.size();
+                out.nodes.emplace_back();
+                nd.child[i] = childSlot[i];
+            }
+        }
+        out.nodes[slot] = nd;
+        for (int i = 0; i < n; ++i)
+            if (b.nodes[kids[i]].left >= 0) emitNode(childSlot[i], kids[i], depth + 1);
+    }
+};
+
+}  // namespace
+
+void buildFastHost(const FastInputs& in, FastHostScene& out) {
+    out.nodes.clear();
+    out.tris.clear();
+    out.maxDepth = 0;
+    out.allIdentity = true;
+
+    // 1. instances reachable from octree node 0, in first-visit order
+    std::vector<uint32_t> instances;
+    if (in.numOct) {
+        std::vector<uint8_t> seen(in.numMeshes, 0);
+        std::vector<uint32_t> stack{0};
+        while (!stack.empty()) {
+            const OctNodeRec& n = in.oct[stack.back()];
+            stack.pop_back();
+            for (uint32_t i = n.meshesStart; i < n.meshesEnd && i < in.numMeshes; ++i)
+                if (!seen[i]) {
+                    seen[i] = 1;
+                    instances.push_back(i);
+                }
+            for (uint32_t c = 0; c < n.numChildren; ++c) stack.push_back(n.firstChild + c);
+        }
+    }
+
+    // 2. their leaf triangles, baked to world space
+    std::vector<Prim> prims;
+    for (uint32_t inst : instances) {
+        const MeshRec& m = in.meshes[inst];
+        const bool ident = isIdentity(m.M);
+        out.allIdentity = out.allIdentity && ident;
+        std::vector<uint32_t> stack{m.bvhNodeStartIdx};
+        while (!stack.empty()) {
+            const BvhNodeRec& n = in.bvh[stack.back()];
+            stack.pop_back();
+            if (n.firstChild != kInvalid) {
+                stack.push_back(n.firstChild);
+                stack.push_back(n.firstChild + 1);
+                continue;
+            }
+            if (n.triStart == kInvalid) continue;
+            for (uint32_t j = n.triStart; j < n.triEnd; ++j) {
+                Prim p;
+                const float* src = in.triPos[j].p;
+                for (int v = 0; v < 3; ++v) {
+                    const float* q = src + 3 * v;
+                    if (ident) {
+                        p.p[3 * v] = q[0]; p.p[3 * v + 1] = q[1]; p.p[3 * v + 2] = q[2];
+                    } else {  // mul(float4(q,1), M): component r runs along memory row r
+                        for (int r = 0; r < 3; ++r)
+                            p.p[3 * v + r] = std::fmaf(m.M[4 * r + 2], q[2], std::fmaf(m.M[4 * r + 1], q[1], m.M[4 * r] * q[0])) + m.M[4 * r + 3];
+                    }
+                    p.box.grow(&p.p[3 * v]);
+                }
+                for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.mn[k] + p.box.mx[k]);
+                bool finite = true;
+                for (float f : p.p) finite = finite && std::isfinite(f);
+                if (!finite) continue;  // can never be hit (every comparison with NaN/inf fails)
+                p.srcTri = j;
+                p.instance = inst;
+                prims.push_back(p);
+            }
+        }
+    }
+
+    out.nodes.emplace_back();
+    Node4& root = out.nodes[0];
+    std::memset(&root, 0, sizeof(root));
+    for (int i = 0; i < 4; ++i) {
+        for (int k = 0; k < 3; ++k) {
+            root.bmin[k][i] = INFINITY;
+            root.bmax[k][i] = -INFINITY;
+        }
+        root.child[i] = kEmptyRef;
+    }
+    if (prims.empty()) return;
+
+    // 3. BVH2
+    Builder b(prims);
+    uint32_t r = b.alloc();
+    b.build(r, 0, (uint32_t)prims.size(), 0);
+
+    // 4. collapse + layout
+    Emitter e{b, out};
+    out.tris.reserve(prims.size());
+    if (b.nodes[r].left < 0) {  // a single leaf: hang it under the root
+        for (int k = 0; k < 3; ++k) {
+            root.bmin[k][0] = b.nodes[r].box.mn[k];
+            root.bmax[k][0] = b.nodes[r].box.mx[k];
+        }
+        out.nodes[0].child[0] = e.emitLeaf(b.nodes[r]);
+        out.maxDepth = 1;
+        return;
+    }
+    e.emitNode(0, (int32_t)r, 1);
+    out.maxDepth = e.maxDepth;
+}
+
+}  // namespace okrt

@@ -43,3 +43,27 @@ def test_small_mesh_scene_reference_order_counters_match(oracle):
     for k in ("n_oct", "n_mesh", "n_node", "n_tri", "mesh_hits", "tex_taps"):
         assert abs(gc[k] - cc[k]) <= 0.002 * max(cc[k], 1) + 8, (k, gc[k], cc[k])
     assert (np.abs(gr.astype(int) - cr.astype(int)) > 1).mean() < 0.005
+
+
+def test_fast_traversal_matches_oracle_small_scene(oracle):
+    desc = scenes.small_mesh_scene(with_lights=True)
+    (ga, gr, gc), (ca, cr, cc) = render_both(oracle, desc, 160, 90, traversal=abi.TRAVERSAL_FAST)
+    frac, rmse, nanmm, _ = compare_accum(ga, ca)
+    assert frac >= 0.995 and rmse <= 0.02 and nanmm <= 1e-5, (frac, rmse, nanmm)
+    for k in ("pixels", "segments", "mesh_hits", "sphere_hits", "tex_taps", "env_taps"):
+        assert abs(gc[k] - cc[k]) <= 0.002 * max(cc[k], 1) + 8, (k, gc[k], cc[k])
+
+
+def test_fast_equals_reference_order_on_gpu():
+    """Same device, same libm: the two traversals must agree bit for bit except equal-distance ties."""
+    desc = scenes.small_mesh_scene(seed=5, n_objects=8, detail=16, with_lights=False)
+    accs = []
+    for trav in (abi.TRAVERSAL_REFERENCE, abi.TRAVERSAL_FAST):
+        rt, _, _ = scenes.instantiate(desc, 320, 180)
+        rt.ctx.set_option(abi.OPT_TRAVERSAL, trav)
+        for _ in range(2):
+            rt.render()
+        accs.append(rt.ctx.read_accum())
+        rt.close()
+    same = (accs[0] == accs[1]).all(-1) | (np.isnan(accs[0]).any(-1) & np.isnan(accs[1]).any(-1))
+    assert same.mean() >= 0.999, same.mean()
