@@ -8,7 +8,8 @@
 //                  GPU-Utilities.hlsli:124) + source triangle index (into t0/t1) + instance index.
 //                  One test = 3 x global_load_dwordx4.
 // Child reference: bit 31 set = leaf {count-1 : 4 bits, first triangle : 27 bits}; else node index;
-// kEmptyRef = unused slot (its box is inverted and can never be hit).
+// kEmptyRef = unused slot (its box is NaN, so every slab comparison fails; an inverted +-inf box
+// would NOT do: min/max un-invert it and every ray hits it).
 #pragma once
 #include <string>
 #include <vector>

@@ -210,10 +210,7 @@ struct Emitter {
         uint32_t childSlot[4];
         for (int i = 0; i < 4; ++i) {
             if (i >= n) {
-                for (int k = 0; k < 3; ++k) {
-                    nd.bmin[k][i] = INFINITY;
-                    nd.bmax[k][i] = -INFINITY;
-                }
+                for (int k = 0; k < 3; ++k) nd.bmin[k][i] = nd.bmax[k][i] = NAN;  // every slab comparison fails
                 nd.child[i] = kEmptyRef;
                 continue;
             }
@@ -306,10 +303,7 @@ void buildFastHost(const FastInputs& in, FastHostScene& out) {
     Node4& root = out.nodes[0];
     std::memset(&root, 0, sizeof(root));
     for (int i = 0; i < 4; ++i) {
-        for (int k = 0; k < 3; ++k) {
-            root.bmin[k][i] = INFINITY;
-            root.bmax[k][i] = -INFINITY;
-        }
+        for (int k = 0; k < 3; ++k) root.bmin[k][i] = root.bmax[k][i] = NAN;
         root.child[i] = kEmptyRef;
     }
     if (prims.empty()) return;
@@ -336,3 +330,83 @@ void buildFastHost(const FastInputs& in, FastHostScene& out) {
 }
 
 }  // namespace okrt
+
+// ---- host-side check of the structure (no GPU): used by tests/test_fast_structure.py ----------------
+// Builds the structure from raw reference tables and traces rays through it on the CPU with the
+// same node/leaf decoding as the kernel. Not used by any render path.
+extern "C" int okrt_debug_fast_closest_hit(const void* triPos, uint32_t numTris, const void* bvh, uint32_t numNodes, const void* oct,
+                                           uint32_t numOct, const void* meshes, uint32_t numMeshes, uint32_t numRays,
+                                           const float* origins, const float* dirs, float* outDist, uint32_t* outTri,
+                                           uint32_t* outInstance, uint32_t* outStats) {
+    using namespace okrt;
+    FastInputs in{(const TriangleRec*)triPos, numTris, (const BvhNodeRec*)bvh, numNodes, (const OctNodeRec*)oct, numOct, (const MeshRec*)meshes, numMeshes};
+    FastHostScene fs;
+    buildFastHost(in, fs);
+    if (outStats) {
+        outStats[0] = (uint32_t)fs.nodes.size();
+        outStats[1] = (uint32_t)fs.tris.size();
+        outStats[2] = fs.maxDepth;
+        outStats[3] = fs.allIdentity ? 1u : 0u;
+    }
+    auto dot = [](const float* a, const float* b) { return std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])); };
+    auto cross = [](const float* a, const float* b, float* r) {
+        r[0] = std::fmaf(a[1], b[2], -(a[2] * b[1]));
+        r[1] = std::fmaf(a[2], b[0], -(a[0] * b[2]));
+        r[2] = std::fmaf(a[0], b[1], -(a[1] * b[0]));
+    };
+    for (uint32_t r = 0; r < numRays; ++r) {
+        const float* o = origins + 3 * r;
+        float d[3] = {dirs[3 * r], dirs[3 * r + 1], dirs[3 * r + 2]};
+        float rs = 1.0f / std::sqrt(dot(d, d));
+        for (float& x : d) x *= rs;
+        float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
+        float best = FLT_MAX;
+        uint32_t bt = kInvalid, bi = kInvalid;
+        std::vector<uint32_t> stack{0};
+        while (!stack.empty()) {
+            uint32_t cur = stack.back();
+            stack.pop_back();
+            if (cur == kEmptyRef) continue;
+            if (cur & kLeafBit) {
+                uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
+                for (uint32_t j = 0; j < count; ++j) {
+                    const Tri48& t = fs.tris[first + j];
+                    float c1[3], c2[3], mv[3] = {o[0] - t.p2[0], o[1] - t.p2[1], o[2] - t.p2[2]};
+                    cross(d, t.e2, c1);
+                    float det = dot(t.e1, c1);
+                    if (det < 0.000001f && det > -0.000001f) continue;
+                    float id = 1.f / det;
+                    float u = dot(mv, c1) * id;
+                    if (u < -0.000001f) continue;
+                    cross(mv, t.e1, c2);
+                    float v = dot(d, c2) * id;
+                    if (v < -0.000001f || u + v > 1.0f) continue;
+                    float tt = dot(t.e2, c2) * id;
+                    if (tt < -0.000001f || !(tt > 0.f)) continue;
+                    float w[3] = {d[0] * tt, d[1] * tt, d[2] * tt};
+                    float dist = std::sqrt(dot(w, w));
+                    if (dist < best) {
+                        best = dist;
+                        bt = t.srcTri;
+                        bi = t.instance;
+                    }
+                }
+                continue;
+            }
+            const Node4& n = fs.nodes[cur];
+            for (int k = 0; k < 4; ++k) {
+                float tn = -FLT_MAX, tf = FLT_MAX;
+                for (int a = 0; a < 3; ++a) {
+                    float t0 = (n.bmin[a][k] - o[a]) * inv[a], t1 = (n.bmax[a][k] - o[a]) * inv[a];
+                    tn = std::fmax(tn, std::fmin(t0, t1));
+                    tf = std::fmin(tf, std::fmax(t0, t1));
+                }
+                if (tf >= tn && tf > 0.f && tn < best) stack.push_back(n.child[k]);
+            }
+        }
+        outDist[r] = best;
+        outTri[r] = bt;
+        outInstance[r] = bi;
+    }
+    return 0;
+}

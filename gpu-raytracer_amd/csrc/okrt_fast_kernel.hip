@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                 float az = (bminz[k] - ro.z) * inv.z, bz = (bmaxz[k] - ro.z) * inv.z;
                 float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
                 float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-                bool hit = tfar >= tnear && tfar > 0.f && tnear < best;
+                bool hit = tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef;
                 tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
             }
             // sort the four (distance, child) pairs ascending: 5-comparator network

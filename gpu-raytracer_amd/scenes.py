@@ -358,7 +358,7 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
         return fn
 
     # floor (1) + ceiling ring (4) + outer walls (4 x 2 storeys = 8)
-    add(grid_surface(relief(lambda U, V: np.stack([X0 + U * (X1 - X0), np.full_like(U, Y0), Z0 + V * (Z1 - Z0)], -1), 1, 0.4, 1), d(160), d(100), (24, 16), flip=True), 0)
+    add(grid_surface(relief(lambda U, V: np.stack([X0 + U * (X1 - X0), np.full_like(U, Y0), Z0 + V * (Z1 - Z0)], -1), 1, 0.4, 1), d(120), d(75), (24, 16), flip=True), 0)
     for k, (xa, xb, za, zb) in enumerate([(X0, X1, Z0, Z0 + 30), (X0, X1, Z1 - 30, Z1), (X0, X0 + 30, Z0 + 30, Z1 - 30), (X1 - 30, X1, Z0 + 30, Z1 - 30)]):
         add(grid_surface(lambda U, V, xa=xa, xb=xb, za=za, zb=zb: np.stack([xa + U * (xb - xa), np.full_like(U, Y1), za + V * (zb - za)], -1), d(40), d(24), (8, 4)), 1)
     for storey in range(2):
@@ -367,11 +367,11 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
             if k < 2:
                 z = Z0 if k == 0 else Z1
                 fn = relief(lambda U, V, z=z, ya=ya, yb=yb: np.stack([X0 + U * (X1 - X0), ya + V * (yb - ya), np.full_like(U, z)], -1), 2, 1.2, 10 + k)
-                add(grid_surface(fn, d(150), d(40), (16, 4), flip=(k == 0)), 2 + storey)
+                add(grid_surface(fn, d(100), d(24), (16, 4), flip=(k == 0)), 2 + storey)
             else:
                 x = X0 if k == 2 else X1
                 fn = relief(lambda U, V, x=x, ya=ya, yb=yb: np.stack([np.full_like(U, x), ya + V * (yb - ya), Z0 + U * (Z1 - Z0)], -1), 0, 1.2, 10 + k)
-                add(grid_surface(fn, d(100), d(40), (12, 4), flip=(k == 3)), 2 + storey)
+                add(grid_surface(fn, d(100), d(16), (12, 4), flip=(k == 3)), 2 + storey)
 
     # arcades: 2 sides x 2 storeys x 14 columns, each column = base + shaft + capital (168 meshes)
     ncol = 14
@@ -383,7 +383,7 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
             for cx in col_x:
                 add(box_mesh((cx - 3.2, yb0, zc - 3.2), (cx + 3.2, yb0 + 2.5, zc + 3.2), d(3)), 4)
                 shaft = lambda V, hgt=hgt: (2.1 - 0.35 * V + 0.12 * np.cos(V * 40), 2.5 + V * (hgt - 6.0))
-                add(revolve(shaft, d(28), d(18), centre=(cx, yb0, zc), uv_scale=(2, 6)), 5 + storey)
+                add(revolve(shaft, d(24), d(14), centre=(cx, yb0, zc), uv_scale=(2, 6)), 5 + storey)
                 cap = lambda V: (1.8 + 1.6 * V ** 2, V * 3.5)
                 add(revolve(cap, d(24), d(6), centre=(cx, yb0 + hgt - 3.5, zc), uv_scale=(2, 1)), 7)
     # arches between columns: 2 sides x 2 storeys x 13 (52 meshes)
@@ -398,7 +398,7 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
                     r = (xb - xa) * 0.5 - 1.0
                     cxm = (xa + xb) * 0.5
                     return np.stack([cxm - r * np.cos(ang), ytop - 9.0 + r * 0.55 * np.sin(ang), zc - 3.0 + V * 6.0], -1)
-                add(grid_surface(arch, d(36), d(8), (4, 1)), 8 + storey)
+                add(grid_surface(arch, d(34), d(8), (4, 1)), 8 + storey)
     # galleries' floor slabs (2) + balustrades (2 sides x 13 = 26)
     for side, (za, zb) in enumerate(((Z0, -30.0), (26.0, Z1))):
         add(box_mesh((X0, 40.0, za), (X1, 42.0, zb), d(10), 6.0), 10)
@@ -415,7 +415,7 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
                 y = 74.0 - V * 44.0
                 z = zc + 1.5 * np.sin(U * 9 + k) * V + 2.5 * np.sin(V * 5 + U * 3 + k) * V
                 return np.stack([x, y, z], -1)
-            add(grid_surface(cloth, d(40), d(90), (1, 3)), 12 + (k % 3), dict(kind="fabric"))
+            add(grid_surface(cloth, d(24), d(60), (1, 3)), 12 + (k % 3), dict(kind="fabric"))
     # long curtains on the upper gallery: 10
     for side, zc in enumerate((-36.5, 32.5)):
         for k in range(5):
@@ -426,7 +426,7 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
                 y = 78.0 - V * 34.0
                 z = zc + 1.2 * np.sin(U * 40 + k) * (0.3 + V)
                 return np.stack([x, y, z], -1)
-            add(grid_surface(curtain, d(90), d(40), (3, 3)), 15 + (k % 3), dict(kind="fabric"))
+            add(grid_surface(curtain, d(60), d(24), (3, 3)), 15 + (k % 3), dict(kind="fabric"))
     # ornaments: lion-head blobs (2), vases (16 = body) with plants (16), roof beams (12), lamps (8)
     for k, x in enumerate((X0 + 4.0, X1 - 4.0)):
         def head(U, V, x=x, k=k):
@@ -434,18 +434,18 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
             dd = np.stack([np.sin(ph) * np.cos(th), np.cos(ph), np.sin(ph) * np.sin(th)], -1)
             r = 6.0 + 3.0 * fbm3(dd * 2.5 + k * 5.0, 77 + k, 3)
             return dd * r[..., None] + np.array([x, 22.0, -2.0])
-        add(grid_surface(head, d(120), d(60), (2, 1)), 18)
+        add(grid_surface(head, d(80), d(40), (2, 1)), 18)
     vase_pos = [(x, z) for x in np.linspace(X0 + 35, X1 - 35, 8) for z in (-18.0, 14.0)]
     for (vx, vz) in vase_pos:
         body = lambda V: (2.0 + 1.8 * np.sin(V * 3.0) * (1 - 0.5 * V), V * 9.0)
-        add(revolve(body, d(32), d(16), centre=(vx, Y0, vz), uv_scale=(2, 1)), 19)
+        add(revolve(body, d(24), d(12), centre=(vx, Y0, vz), uv_scale=(2, 1)), 19)
 
         def plant(U, V, vx=vx, vz=vz):
             th, ph = U * 2 * np.pi, V * np.pi
             dd = np.stack([np.sin(ph) * np.cos(th), np.cos(ph), np.sin(ph) * np.sin(th)], -1)
             r = 3.5 + 2.5 * fbm3(dd * 4.0 + vx, 31, 3)
             return dd * r[..., None] + np.array([vx, Y0 + 13.0, vz])
-        add(grid_surface(plant, d(40), d(20), (3, 2)), 20)
+        add(grid_surface(plant, d(28), d(14), (3, 2)), 20)
     for k, x in enumerate(np.linspace(X0 + 20, X1 - 20, 12)):
         add(box_mesh((x - 1.5, Y1 - 6.0, -30.0), (x + 1.5, Y1 - 3.0, 26.0), d(6), 4.0), 21)
     for k, x in enumerate(np.linspace(X0 + 50, X1 - 50, 4)):
