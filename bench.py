@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s + ms/frame of the path-tracing hot path on N MI355X (one process per GPU).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sponza|sponza4k|dragon|dragon80k|glass|spheres]
+
+A "step" is one frame = one sample per pixel of the whole frame. N = 1: the workload is
+BASELINE.json's headline config (Sponza-class 1920x1080, configs[3]; procedural stand-in of
+262 267 triangles / 390 meshes / 26 textures). N > 1 (launched by
+torch.distributed.run): the SAME frame is split into interleaved 8-row stripes, rank r owns stripes
+r, r+N, ...; scene tables are replicated; there is no data-path collective per frame — the per-rank
+float4 accumulation tiles are gathered to rank 0 over RCCL every 16 frames and after the last one
+(inside the timed region). Total work is fixed, so "scaling" is "strong".
+
+The JSON line carries the roofline of the dominant kernel family (BVH traversal) and a CPU baseline
+(the scalar oracle on this box's host cores, bounded sample, rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:36)
+STRIPE_ROWS = 8
+GATHER_EVERY = 16
+
+WORKLOADS = {
+    # name: (scene builder kwargs, width, height, description)
+    "sponza": ("sponza_proxy", {}, 1920, 1080, "sponza-proxy 262267 tris/390 meshes/26 tex, 1920x1080, 1 spp/frame, NUM_BOUNCES=1"),
+    "sponza4k": ("sponza_proxy", {}, 3840, 2160, "sponza-proxy 262267 tris/390 meshes/26 tex, 3840x2160, 1 spp/frame, NUM_BOUNCES=1"),
+    "dragon": ("dragon_proxy", {"num_triangles": 871414}, 1280, 720, "dragon-proxy 871414 tris, diffuse, 1280x720"),
+    "dragon80k": ("dragon_proxy", {"num_triangles": 80000}, 1280, 720, "dragon-proxy 80000 tris, diffuse, 1280x720"),
+    "glass": ("glass_revolver_proxy", {}, 1920, 1080, "glass + revolver-proxy + IBL, 1920x1080"),
+    "spheres": ("test_scene_spheres", {}, 256, 256, "TestScene 4 spheres 256x256"),
+}
+
+
+def algorithmic_bytes(c):
+    """bytes the reference's own structures would move for these counters."""
+    traversal = 48 * c["n_oct"] + 232 * c["n_mesh"] + 36 * c["n_node"] + 36 * c["n_tri"]
+    shading = 132 * c["mesh_hits"] + 16 * c["tex_taps"] + 16 * c["env_taps"] + 36 * c["pixels"]
+    return traversal, shading
+
+
+def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
+    """The scalar oracle (oracle/liboracle.so) on the host cores, on a bounded sample of the same frame:
+    every `stride`-th row, stride chosen from a short calibration run to cost about `target_seconds`."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import conftest
+    oracle = conftest.Oracle()
+    rt, scene, res = oracle.instantiate(desc, width, height)
+    rt.calculateProjectionData()
+    rt.updateBuffers()
+    rd = rt.render_data
+    cores = os.cpu_count() or 1
+    abi = conftest.abi
+
+    def run(stride):
+        rt.ctx.set_tile(1, 0, stride)
+        rt.ctx.set_option(abi.OPT_COUNTERS, 1)
+        rt.ctx.reset_counters()
+        t0 = time.perf_counter()
+        rt.ctx.render(rd)
+        dt = time.perf_counter() - t0
+        return rt.ctx.counters()["segments"], dt, rt.ctx.tile_rows()
+
+    rays, dt, rows = run(max(height // 16, 1))  # calibration: ~16 rows
+    rate = rays / max(dt, 1e-6)
+    full_rays = rays * (height / max(rows, 1))
+    stride = max(1, int(round(full_rays / (rate * target_seconds))))
+    rays, dt, rows = run(stride)
+    rt.close()
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (scalar C++ restatement, reference traversal order), every {stride}th row of the same {width}x{height} frame "
+                      f"({rows} rows, {rays} rays) in {dt:.1f} s on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    abi = importlib.import_module("gpu-raytracer_amd._abi")
+    scenes = importlib.import_module("gpu-raytracer_amd.scenes")
+    fns = abi.load_device_library()  # raises if libokrt.so is missing: no fallback
+
+    builder, kwargs, W, H, wl_desc = WORKLOADS[args.workload]
+    desc = getattr(scenes, builder)(**kwargs)
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rt, scene, res = scenes.instantiate(desc, W, H, device=local_rank)
+    ctx = rt.ctx
+    ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
+
+    accum_t = gathered = None
+    if world > 1:
+        ctx.set_tile(STRIPE_ROWS, rank, world)
+        rows = ctx.tile_rows()
+        max_rows = 0
+        for r in range(world):  # every rank pads its tile to the largest one so gather sizes match
+            n = sum(min(STRIPE_ROWS, H - s * STRIPE_ROWS) for s in range(r, (H + STRIPE_ROWS - 1) // STRIPE_ROWS, world))
+            max_rows = max(max_rows, n)
+        # the framebuffer lives in a torch tensor so RCCL can move it; okrt renders straight into it, on torch's stream
+        accum_t = torch.zeros((max_rows, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+        result_t = torch.zeros((max_rows, W), dtype=torch.int32, device=f"cuda:{local_rank}")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.bind_framebuffers(accum_t.data_ptr(), result_t.data_ptr())
+        if rank == 0:
+            gathered = [torch.empty_like(accum_t) for _ in range(world)]
+
+    def gather_tiles():
+        if world > 1:
+            dist.gather(accum_t, gathered if rank == 0 else None, dst=0)
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    # ---- roofline numerator: the reference-order counters of one frame of this workload -------
+    ref_counters = None
+    if rank == 0 or world > 1:
+        ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_REFERENCE)
+        ctx.set_option(abi.OPT_COUNTERS, 1)
+        ctx.reset_counters()
+        rt.render()
+        ref_counters = ctx.counters()
+        ctx.set_option(abi.OPT_COUNTERS, 0)
+        ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
+        rt.resetAccumulation()
+
+    # ---- warm-up, then exactly K timed steps ----------------------------------------------------
+    for _ in range(args.warmup):
+        rt.render()
+    sync()
+    ctx.reset_counters()
+    ctx.set_option(abi.OPT_TIMING, args.steps)  # HIP events around every kernel, on the stream they run on
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        rt.render()
+        if (k + 1) % GATHER_EVERY == 0 and k + 1 != args.steps:
+            gather_tiles()
+    gather_tiles()
+    sync()
+    elapsed = time.perf_counter() - t0
+    trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
+    ctx.set_option(abi.OPT_TIMING, 0)
+    rays_local = ctx.counters()["segments"]
+
+    rays_total, elapsed_max = rays_local, elapsed
+    if world > 1:
+        t = torch.tensor([float(rays_local), 0.0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rays_total = int(t[0].item())
+        tm = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        elapsed_max = float(tm.item())
+        ref_t = torch.tensor([float(ref_counters[k]) for k in sorted(ref_counters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(ref_t, op=dist.ReduceOp.SUM)
+        ref_counters = {k: int(v) for k, v in zip(sorted(ref_counters), ref_t.tolist())}
+        st = torch.tensor([trace_ms, shade_ms, other_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        trace_ms, shade_ms, other_ms = st.tolist()
+
+    if rank == 0:
+        ms_per_step = elapsed_max * 1e3 / args.steps
+        mrays = rays_total / elapsed_max / 1e6
+        trav_bytes, shade_bytes = algorithmic_bytes(ref_counters)
+        frames = max(timed_frames, 1)
+        trace_ms_frame = trace_ms / frames
+        achieved = trav_bytes / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0  # GB/s, whole frame's traversal
+        out = {
+            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps,
+                       "tile_split": f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks" if world > 1 else "full frame",
+                       "gather": f"RCCL gather of float4 tiles to rank 0 every {GATHER_EVERY} frames + final" if world > 1 else "none"},
+            "roofline": {
+                "bound": "hbm", "kernel": "traceKernel (BVH traversal, primary + queued launches of one frame)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_frame": trav_bytes, "algorithmic_bytes_per_ray": round(trav_bytes / max(ref_counters["segments"], 1), 1),
+                "kernel_ms_per_frame": round(trace_ms_frame, 4), "shade_ms_per_frame": round(shade_ms / frames, 4),
+                "other_ms_per_frame": round(other_ms / frames, 4),
+                "frame_frac": round((trav_bytes + shade_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "algorithmic bytes = what the REFERENCE's octree->mesh->BVH traversal order touches for the same rays "
+                        "(SURVEY.md 8d); the derived BVH4 visits far fewer, so frac may exceed 1"},
+        }
+        pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and args.workload == "sponza" and world == 1:
+            try:
+                out["roofline"]["traffic"] = json.load(open(pmc)).get("trace_hbm_bytes_per_frame")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, W, H, None)
+        print(json.dumps(out), flush=True)
+
+    rt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,7 @@ PRODUCT_ONLY = {
     "timer_end": (C.c_int, [P]),
     "timer_elapsed_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "last_render_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
+    "get_stage_ms": (C.c_int, [P, C.POINTER(C.c_float * 3), C.POINTER(U32)]),
     "get_api": (P, []),
 }
 HEADER_SYMBOLS = ["okrt_" + n for n in list(SIGNATURES) + list(PRODUCT_ONLY)]

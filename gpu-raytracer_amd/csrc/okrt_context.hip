@@ -49,8 +49,11 @@ struct okrt_ctx {
     bool tablesValid = false;
     FastScene* fast = nullptr;  // derived structure (okrt_fast.h); rebuilt when geometry changes
     bool fastDirty = true;
-    hipEvent_t evBegin = nullptr, evEnd = nullptr, evR0 = nullptr, evR1 = nullptr;
-    bool lastRenderTimed = false;
+    hipEvent_t evBegin = nullptr, evEnd = nullptr;
+    // OKRT_OPT_TIMING: ring of per-render event lists (kernel boundaries, in launch order)
+    struct TimedFrame { std::vector<hipEvent_t> ev; int used = 0; bool fast = false; };
+    std::vector<TimedFrame> ring;
+    size_t ringNext = 0, ringCount = 0;
     std::string err;
 };
 
@@ -193,8 +196,6 @@ okrt_status okrt_create(int device, okrt_ctx** out) {
     c->stream = c->ownStream;
     hipEventCreate(&c->evBegin);
     hipEventCreate(&c->evEnd);
-    hipEventCreate(&c->evR0);
-    hipEventCreate(&c->evR1);
     if (hipMalloc(&c->counters.ptr, kNumCounters * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return OKRT_ERR_OOM;
@@ -214,8 +215,10 @@ okrt_status okrt_destroy(okrt_ctx* c) {
     for (DeviceBuffer* b : {&c->textures, &c->env, &c->accumOwn, &c->resultOwn, &c->counters})
         if (b->ptr) hipFree(b->ptr);
     fastDestroy(c->fast);
-    for (hipEvent_t e : {c->evBegin, c->evEnd, c->evR0, c->evR1})
+    for (hipEvent_t e : {c->evBegin, c->evEnd})
         if (e) hipEventDestroy(e);
+    for (auto& f : c->ring)
+        for (hipEvent_t e : f.ev) hipEventDestroy(e);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
     return OKRT_OK;
@@ -367,11 +370,29 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
 
     SceneView view = makeView(c);
     unsigned long long* counters = c->countersOn ? (unsigned long long*)c->counters.ptr : nullptr;
-    if (c->timingOn) OKRT_HIP(c, hipEventRecord(c->evR0, c->stream));
+    okrt_ctx::TimedFrame* tf = nullptr;
+    if (c->timingOn && !c->ring.empty()) {
+        tf = &c->ring[c->ringNext];
+        c->ringNext = (c->ringNext + 1) % c->ring.size();
+        c->ringCount = std::min(c->ringCount + 1, c->ring.size());
+        const size_t need = 2 * (size_t)(c->maxBounces + 1) + 1;
+        while (tf->ev.size() < need) {
+            hipEvent_t e;
+            OKRT_HIP(c, hipEventCreate(&e));
+            tf->ev.push_back(e);
+        }
+        tf->used = 0;
+    }
     // The debug heat maps count the REFERENCE traversal's box/triangle checks (RaytracerCS.hlsl:516-520),
     // so those frames always run the reference-order kernel.
     if (c->traversal == OKRT_TRAVERSAL_REFERENCE || rd->debugMode != 0) {
+        if (tf) OKRT_HIP(c, hipEventRecord(tf->ev[0], c->stream));
         launchReferenceOrder(view, *rd, c->tile, c->accum, c->result, counters, c->stream);
+        if (tf) {
+            OKRT_HIP(c, hipEventRecord(tf->ev[1], c->stream));
+            tf->used = 2;
+            tf->fast = false;
+        }
     } else {
         if (c->fastDirty) {
             std::string msg;
@@ -389,12 +410,16 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
             c->fastDirty = false;
         }
         std::string msg;
-        if (!launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, c->stream, msg)) return fail(c, OKRT_ERR_OOM, "fast pipeline: " + msg);
+        if (!launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, (unsigned long long*)c->counters.ptr, c->stream,
+                        tf ? tf->ev.data() : nullptr, msg))
+            return fail(c, OKRT_ERR_OOM, "fast pipeline: " + msg);
+        if (tf) {
+            tf->used = 2 * (c->maxBounces + 1) + 1;
+            tf->fast = true;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
-    if (c->timingOn) OKRT_HIP(c, hipEventRecord(c->evR1, c->stream));
-    c->lastRenderTimed = c->timingOn;
     return OKRT_OK;
 }
 
@@ -435,7 +460,16 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             c->maxBounces = (int)value;
             return OKRT_OK;
         case OKRT_OPT_COUNTERS: c->countersOn = value != 0; return OKRT_OK;
-        case OKRT_OPT_TIMING: c->timingOn = value != 0; return OKRT_OK;
+        case OKRT_OPT_TIMING: {
+            if (value < 0 || value > 4096) return fail(c, OKRT_ERR_INVALID_ARG, "timing: ring size 0..4096");
+            OKRT_HIP(c, hipSetDevice(c->device));
+            OKRT_HIP(c, hipStreamSynchronize(c->stream));
+            c->timingOn = value != 0;
+            c->ring.resize((size_t)value > c->ring.size() ? (size_t)value : c->ring.size());
+            if (value) c->ring.resize((size_t)value);
+            c->ringNext = c->ringCount = 0;
+            return OKRT_OK;
+        }
         default: return fail(c, OKRT_ERR_INVALID_ARG, "unknown option");
     }
 }
@@ -483,12 +517,44 @@ okrt_status okrt_timer_elapsed_ms(okrt_ctx* c, float* out_ms) {
     OKRT_HIP(c, hipEventElapsedTime(out_ms, c->evBegin, c->evEnd));
     return OKRT_OK;
 }
+static okrt_status frameStages(okrt_ctx* c, const okrt_ctx::TimedFrame& f, float out[3]) {
+    out[0] = out[1] = out[2] = 0.f;
+    if (f.used < 2) return OKRT_OK;
+    OKRT_HIP(c, hipEventSynchronize(f.ev[f.used - 1]));
+    float total = 0.f;
+    OKRT_HIP(c, hipEventElapsedTime(&total, f.ev[0], f.ev[f.used - 1]));
+    for (int k = 0; k + 1 < f.used; ++k) {
+        float ms = 0.f;
+        OKRT_HIP(c, hipEventElapsedTime(&ms, f.ev[k], f.ev[k + 1]));
+        out[f.fast ? (k & 1) : 0] += ms;  // fast pipeline alternates trace, shade, trace, shade ...
+    }
+    out[2] = total - out[0] - out[1];
+    return OKRT_OK;
+}
+
 okrt_status okrt_last_render_ms(okrt_ctx* c, float* out_ms) {
     if (!c || !out_ms) return OKRT_ERR_INVALID_ARG;
-    if (!c->lastRenderTimed) return fail(c, OKRT_ERR_STATE, "last_render_ms: enable OKRT_OPT_TIMING before rendering");
+    if (!c->timingOn || !c->ringCount) return fail(c, OKRT_ERR_STATE, "last_render_ms: enable OKRT_OPT_TIMING before rendering");
     OKRT_HIP(c, hipSetDevice(c->device));
-    OKRT_HIP(c, hipEventSynchronize(c->evR1));
-    OKRT_HIP(c, hipEventElapsedTime(out_ms, c->evR0, c->evR1));
+    const okrt_ctx::TimedFrame& f = c->ring[(c->ringNext + c->ring.size() - 1) % c->ring.size()];
+    float st[3];
+    okrt_status s = frameStages(c, f, st);
+    *out_ms = st[0] + st[1] + st[2];
+    return s;
+}
+
+okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames) {
+    if (!c || !out_ms || !out_frames) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    out_ms[0] = out_ms[1] = out_ms[2] = 0.f;
+    *out_frames = 0;
+    for (size_t i = 0; i < c->ringCount; ++i) {
+        float st[3];
+        okrt_status s = frameStages(c, c->ring[i], st);
+        if (s != OKRT_OK) return s;
+        for (int k = 0; k < 3; ++k) out_ms[k] += st[k];
+        *out_frames += 1;
+    }
     return OKRT_OK;
 }
 

@@ -61,7 +61,10 @@ struct FastScene;  // device-resident structure + the wavefront queues
 bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std::string& err);
 void fastDestroy(FastScene* scene);
 // One frame through the wavefront pipeline. Returns false (with err) if queue memory cannot be had.
+// `counters` (optional) = full okrt_counters accounting; `rayTotals` (always) = the same buffer, of which
+// only pixels/segments are bumped, by one atomic per trace launch. `events` (optional): 2*(max_bounces+1)+1 events recorded before/after every kernel, in launch order.
 bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum,
-                uint32_t* result, unsigned long long* counters, hipStream_t stream, std::string& err);
+                uint32_t* result, unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events,
+                std::string& err);
 
 }  // namespace okrt

@@ -65,12 +65,17 @@ OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t
 template <bool PRIMARY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
                                                             HitBuffer hb, const uint32_t* qCount, uint32_t* cursor,
-                                                            unsigned long long* counters) {
+                                                            unsigned long long* counters, unsigned long long* rayTotals) {
     __shared__ uint32_t sRef[kLdsStack][kTraceThreads];
     __shared__ float sDist[kLdsStack][kTraceThreads];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     uint2* myOverflow = fv.overflow + (size_t)(blockIdx.x * kTraceThreads + tid) * fv.overflowCap;
     const uint32_t total = PRIMARY ? (((tile.W + 7) >> 3) * ((tile.rows + 7) >> 3)) << 6 : *qCount;
+    if (!COUNT && blockIdx.x == 0 && tid == 0) {  // rays of this launch, always counted (okrt_counters.pixels / .segments)
+        const unsigned long long n = PRIMARY ? (unsigned long long)tile.W * tile.rows : (unsigned long long)total;
+        if (PRIMARY) atomicAdd(&rayTotals[0], n);
+        atomicAdd(&rayTotals[1], n);
+    }
 
     uint32_t rayIdx = kInvalid;   // the ray this lane is tracing
     uint32_t cur = kDone;         // node/leaf reference being processed, kDone = lane idle
@@ -414,7 +419,7 @@ void fastDestroy(FastScene* fs) {
 }
 
 bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
-                unsigned long long* counters, hipStream_t stream, std::string& err) {
+                unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, std::string& err) {
     const size_t items = (size_t)(((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;
     if (items > fs.capacity) {
         hipStreamSynchronize(stream);
@@ -433,27 +438,34 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     const dim3 tb(kTraceThreads), tg(fs.traceBlocks);
     const dim3 sg((unsigned)((items + 255) / 256));
     const bool cnt = counters != nullptr;
+    int ev = 0;
+    auto mark = [&]() { if (events) hipEventRecord(events[ev++], stream); };
+    mark();
     // segment 0
     if (cnt)
-        hipLaunchKernelGGL((traceKernel<true, true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.counts + 16, counters);
+        hipLaunchKernelGGL((traceKernel<true, true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.counts + 16, counters, rayTotals);
     else
-        hipLaunchKernelGGL((traceKernel<true, false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.counts + 16, counters);
+        hipLaunchKernelGGL((traceKernel<true, false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.counts + 16, counters, rayTotals);
+    mark();
     if (cnt)
         hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.q[1], fs.counts + 1, 0u, lastBounce, accum, result, counters);
     else
         hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.q[1], fs.counts + 1, 0u, lastBounce, accum, result, counters);
+    mark();
     // segments 1..lastBounce: queue b lives in q[b & 1]
     for (uint32_t b = 1; b <= lastBounce; ++b) {
         RayQueue& qin = fs.q[b & 1];
         RayQueue& qout = fs.q[(b + 1) & 1];
         if (cnt)
-            hipLaunchKernelGGL((traceKernel<false, true>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, fs.counts + b, fs.counts + 16 + b, counters);
+            hipLaunchKernelGGL((traceKernel<false, true>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, fs.counts + b, fs.counts + 16 + b, counters, rayTotals);
         else
-            hipLaunchKernelGGL((traceKernel<false, false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, fs.counts + b, fs.counts + 16 + b, counters);
+            hipLaunchKernelGGL((traceKernel<false, false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, fs.counts + b, fs.counts + 16 + b, counters, rayTotals);
+        mark();
         if (cnt)
             hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, fs.counts + b, qout, fs.counts + b + 1, b, lastBounce, accum, result, counters);
         else
             hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, fs.counts + b, qout, fs.counts + b + 1, b, lastBounce, accum, result, counters);
+        mark();
     }
     return true;
 }

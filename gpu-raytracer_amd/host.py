@@ -143,6 +143,13 @@ class Context:
         self._ck(self.fns.timer_elapsed_ms(self.h, C.byref(ms)), "timer_elapsed_ms")
         return ms.value
 
+    def stage_ms(self):
+        """(trace_ms, shade_ms, other_ms, frames) summed over the OKRT_OPT_TIMING ring."""
+        ms = (C.c_float * 3)()
+        n = U32()
+        self._ck(self.fns.get_stage_ms(self.h, C.byref(ms), C.byref(n)), "get_stage_ms")
+        return ms[0], ms[1], ms[2], n.value
+
     def bind_framebuffers(self, accum_ptr, result_ptr):
         self._ck(self.fns.bind_framebuffers(self.h, accum_ptr, result_ptr), "bind_framebuffers")
 

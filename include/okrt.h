@@ -118,9 +118,11 @@ typedef enum okrt_option {
     OKRT_OPT_TRAVERSAL = 0,
     /* NUM_BOUNCES of RaytracerCS.hlsl:6 (default 1 = HEAD; a path has max_bounces+1 segments). */
     OKRT_OPT_MAX_BOUNCES = 1,
-    /* 1 = sum the traversal counters of every render into okrt_counters (default 0). */
+    /* 1 = sum the traversal counters of every render into okrt_counters (default 0). `pixels` and
+     * `segments` are always counted by the fast pipeline (one atomic per kernel launch). */
     OKRT_OPT_COUNTERS = 2,
-    /* 1 = record HIP events around every render's kernels so okrt_last_render_ms works. */
+    /* n > 0 = record HIP events around every kernel of each render (ring of the last n renders) so
+     * okrt_last_render_ms / okrt_get_stage_ms work; 0 = off (default). */
     OKRT_OPT_TIMING = 3
 } okrt_option;
 
@@ -207,6 +209,11 @@ okrt_status okrt_timer_end(okrt_ctx* ctx);
 okrt_status okrt_timer_elapsed_ms(okrt_ctx* ctx, float* out_ms);
 /* With OKRT_OPT_TIMING: device time of the kernels of the most recent okrt_render. */
 okrt_status okrt_last_render_ms(okrt_ctx* ctx, float* out_ms);
+/* With OKRT_OPT_TIMING = n: device time summed over the renders still in the ring (at most n), split
+ * by kernel family: out_ms[0] = traversal kernels (trace primary + queued, or the reference-order
+ * megakernel), out_ms[1] = shading kernels, out_ms[2] = everything else inside the frame (memsets,
+ * gaps). *out_frames = number of renders summed. Synchronises. */
+okrt_status okrt_get_stage_ms(okrt_ctx* ctx, float out_ms[3], uint32_t* out_frames);
 
 /* ---- entry-point table -------------------------------------------------------------------------
  * The same entry points as a struct of function pointers, so a host written against this ABI
