@@ -73,12 +73,26 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
     rays, dt, rows = run(max(height // 16, 1))  # calibration: ~16 rows
     rate = rays / max(dt, 1e-6)
     full_rays = rays * (height / max(rows, 1))
-    stride = max(1, int(round(full_rays / (rate * target_seconds))))
-    rays, dt, rows = run(stride)
+    full_seconds = full_rays / rate
+    if full_seconds > target_seconds:  # few cores: a subset of the rows of one frame
+        stride = max(1, int(round(full_seconds / target_seconds)))
+        rays, dt, rows = run(stride)
+        what = f"every {stride}th row of one {width}x{height} frame ({rows} rows)"
+    else:  # many cores: whole frames, consecutive frame indices, until ~target_seconds
+        frames = max(1, int(target_seconds / full_seconds))
+        rt.ctx.set_tile(height, 0, 1)
+        rt.ctx.set_option(abi.OPT_COUNTERS, 1)
+        rt.ctx.reset_counters()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            rt.updateBuffers()  # numAccumulationFrames += 1, like RayTracer::render
+            rt.ctx.render(rt.render_data)
+        dt = time.perf_counter() - t0
+        rays = rt.ctx.counters()["segments"]
+        what = f"{frames} whole {width}x{height} frames"
     rt.close()
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (scalar C++ restatement, reference traversal order), every {stride}th row of the same {width}x{height} frame "
-                      f"({rows} rows, {rays} rays) in {dt:.1f} s on {cores} threads"}
+            "sample": f"oracle (scalar C++ restatement, reference traversal order): {what}, {rays} rays in {dt:.1f} s on {cores} threads"}
 
 
 def main():
@@ -152,6 +166,11 @@ def main():
         ctx.reset_counters()
         rt.render()
         ref_counters = ctx.counters()
+        ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST)
+        rt.resetAccumulation()
+        ctx.reset_counters()
+        rt.render()  # same frame index through the fast pipeline: its own node / triangle visit counts
+        fast_counters = ctx.counters()
         ctx.set_option(abi.OPT_COUNTERS, 0)
         ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
         rt.resetAccumulation()
@@ -185,6 +204,9 @@ def main():
         ref_t = torch.tensor([float(ref_counters[k]) for k in sorted(ref_counters)], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(ref_t, op=dist.ReduceOp.SUM)
         ref_counters = {k: int(v) for k, v in zip(sorted(ref_counters), ref_t.tolist())}
+        fast_t = torch.tensor([float(fast_counters[k]) for k in sorted(fast_counters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(fast_t, op=dist.ReduceOp.SUM)
+        fast_counters = {k: int(v) for k, v in zip(sorted(fast_counters), fast_t.tolist())}
         st = torch.tensor([trace_ms, shade_ms, other_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
         trace_ms, shade_ms, other_ms = st.tolist()
@@ -196,6 +218,11 @@ def main():
         frames = max(timed_frames, 1)
         trace_ms_frame = trace_ms / frames
         achieved = trav_bytes / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0  # GB/s, whole frame's traversal
+        # what the kernel's OWN algorithm has to move per frame: 128 B per Node4 visit, 48 B per Tri48 test,
+        # 20 B hit record per ray, 32 B queue read per secondary ray (okrt_fast.h)
+        own_bytes = (128 * fast_counters["fast_nodes"] + 48 * fast_counters["fast_tris"] + 20 * fast_counters["segments"]
+                     + 32 * (fast_counters["segments"] - fast_counters["pixels"]))
+        own_achieved = own_bytes / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
@@ -210,9 +237,14 @@ def main():
                 "algorithmic_bytes_per_frame": trav_bytes, "algorithmic_bytes_per_ray": round(trav_bytes / max(ref_counters["segments"], 1), 1),
                 "kernel_ms_per_frame": round(trace_ms_frame, 4), "shade_ms_per_frame": round(shade_ms / frames, 4),
                 "other_ms_per_frame": round(other_ms / frames, 4),
+                "kernel_own_bytes_per_frame": own_bytes, "kernel_own_achieved": round(own_achieved, 1),
+                "kernel_own_frac": round(own_achieved / HBM_PEAK_GBS, 4),
+                "node4_visits_per_ray": round(fast_counters["fast_nodes"] / max(fast_counters["segments"], 1), 2),
+                "tri48_tests_per_ray": round(fast_counters["fast_tris"] / max(fast_counters["segments"], 1), 2),
                 "frame_frac": round((trav_bytes + shade_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "algorithmic bytes = what the REFERENCE's octree->mesh->BVH traversal order touches for the same rays "
-                        "(SURVEY.md 8d); the derived BVH4 visits far fewer, so frac may exceed 1"},
+                        "(SURVEY.md 8d); the derived BVH4 visits far fewer, so frac may exceed 1. kernel_own_* prices the "
+                        "bytes the fast kernel's own node/triangle visits move (mostly L2/Infinity-Cache hits, see traffic)"},
         }
         pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and args.workload == "sponza" and world == 1:
