@@ -2,8 +2,8 @@
 
 `DeviceLibrary` binds the product, libokrt.so (HIP, gfx950). It fails loudly when the shared
 library is missing or does not export every symbol the header declares: there is no CPU fallback
-in the product. The same signature table binds the oracle's `okrt_oracle_*` twins for tests
-(`bind(lib, prefix)`), which is why it lives here.
+in the product. `bind(lib, prefix)` applies the same signature table to any library that exports
+these entry points under another prefix (the test suite uses that for its CPU checker).
 """
 import ctypes as C
 import os

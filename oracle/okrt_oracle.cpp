@@ -971,6 +971,20 @@ void okrt_oracle_kat_sample_env(okrt_ctx* c, const float d[3], float out[3]) {
     V3 r = getEnvironmentLight(*c, v3(d), cnt);
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
+// closest hit of one ray through the uploaded tables: out = {distance, bu, bv}, ids = {hitIdx, hitType, triIdx}
+void okrt_oracle_kat_closest_hit(okrt_ctx* c, const okrt_render_data* rd, const float o[3], const float d[3], float out[3], uint32_t ids[3]) {
+    // findClosestHit returns the shaded payload; the raw hit is re-derived here with the same loop order
+    Ray ray{v3(o), v3(d)};
+    uint32_t bb = 0, tri = 0;
+    Counters cnt;
+    Payload p = findClosestHit(*c, *rd, ray, bb, tri, cnt);
+    out[0] = p.distance;
+    out[1] = p.worldPosition.x;
+    out[2] = p.worldNormal.x;
+    ids[0] = p.hit ? 1u : 0u;
+    ids[1] = bb;
+    ids[2] = tri;
+}
 void okrt_oracle_kat_primary_ray(const okrt_render_data* rd, uint32_t px, uint32_t py, float origin[3], float dir[3], uint32_t* seedOut) {
     // createRay + applyDOF only
     uint32_t seed = px + (py + 74813u) * rd->textureDims[0] * (rd->numAccumulationFrames + 1u);

@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: two ranks (gloo) each render their stripes of one frame through the same Context /
+tile API the GPU path uses (the oracle stands in for the device), the tiles are gathered to rank 0 and
+de-interleaved, and the result must be BIT-identical to a single full-frame render (seeds use global
+coordinates, RaytracerCS.hlsl:430)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, abi, scenes
+
+tiling = importlib.import_module("gpu-raytracer_amd.tiling")
+
+
+def test_owned_rows_partition_every_row_once():
+    for H, sr, world in [(1080, 8, 8), (1080, 8, 3), (37, 5, 4), (16, 16, 1), (9, 4, 4)]:
+        allrows = np.concatenate([tiling.owned_rows(H, sr, r, world) for r in range(world)])
+        assert sorted(allrows) == list(range(H))
+        assert tiling.max_owned_rows(H, sr, world) >= H // world
+
+
+def test_tile_api_matches_owned_rows(oracle):
+    ctx = oracle.context()
+    ctx.resize(20, 37)
+    for sr, world in [(5, 4), (8, 2), (37, 1), (1, 3)]:
+        for r in range(world):
+            ctx.set_tile(sr, r, world)
+            assert ctx.tile_rows() == len(tiling.owned_rows(37, sr, r, world))
+    ctx.close()
+
+
+def _rank_main(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    import conftest
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle = conftest.Oracle()
+    desc = conftest.scenes.small_mesh_scene(seed=2, n_objects=4, detail=5, with_lights=True)
+    W, H, SR, FRAMES = 48, 27, 4, 3
+    rt, sc, res = oracle.instantiate(desc, W, H)
+    rt.ctx.set_tile(SR, rank, world)
+    for _ in range(FRAMES):
+        rt.render()
+    tile = rt.ctx.read_accum()
+    pad = tiling.max_owned_rows(H, SR, world)
+    buf = torch.zeros((pad, W, 4), dtype=torch.float32)
+    buf[: tile.shape[0]] = torch.from_numpy(tile)
+    gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0)
+    if rank == 0:
+        full = tiling.deinterleave(gathered, H, SR).numpy()
+        ref_rt, _, _ = oracle.instantiate(desc, W, H)
+        for _ in range(FRAMES):
+            ref_rt.render()
+        ref = ref_rt.ctx.read_accum()
+        np.save(out_path, np.array([np.array_equal(full, ref, equal_nan=True), float(np.nanmax(np.abs(full - ref)))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_split_equals_full_frame(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.npy")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(2, port, out), nprocs=2, join=True)
+    ok, maxdiff = np.load(out)
+    assert ok == 1.0, maxdiff
