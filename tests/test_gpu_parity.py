@@ -1,8 +1,14 @@
-"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same tables/seeds.
+"""GPU parity: the HIP path (through the C ABI / host layer) against the CPU oracle on the same tables and seeds,
+and against the committed golden images.
 
-Tolerances are SURVEY.md §8c's: at 1 spp >= 99.5 % of pixels with per-pixel RGB L2 <= 1e-3 on the
-float accumulation and whole-image RMSE <= 0.02; outliers are flipped stochastic branches / ties
-caused by last-ulp differences between the device libm and glibc (sin/cos/log/exp2/atan2)."""
+Tolerances are SURVEY.md §8c's. 1 spp: >= 99.5 % of pixels with per-pixel RGB L2 <= 1e-3 on the float
+accumulation, whole-image RMSE <= 0.02, NaN pixels coincide (<= 1e-5 mismatch). N >= 256 spp: per-pixel L2 of acc/N
+<= 4/255 for >= 99.9 % of finite pixels, RMSE <= 1/255. The outliers are flipped stochastic branches / equal-distance
+ties caused by last-ulp differences between the device libm and glibc (sin, cos, log, exp2, log2, atan2); every
+other operation follows the same explicit fma/IEEE conventions on both sides."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -10,60 +16,151 @@ from conftest import abi, compare_accum, host, scenes
 
 pytestmark = pytest.mark.gpu
 
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden  # noqa: E402
 
-def render_both(oracle, desc, w, h, frames=1, traversal=abi.TRAVERSAL_REFERENCE, max_bounces=1):
-    out = []
-    for backend in ("gpu", "cpu"):
-        rt, sc, res = (scenes.instantiate(desc, w, h) if backend == "gpu" else oracle.instantiate(desc, w, h))
-        rt.ctx.set_option(abi.OPT_COUNTERS, 1)
-        rt.ctx.set_option(abi.OPT_MAX_BOUNCES, max_bounces)
-        if backend == "gpu":
-            rt.ctx.set_option(abi.OPT_TRAVERSAL, traversal)
-        for _ in range(frames):
-            rt.render()
-        out.append((rt.ctx.read_accum(), rt.ctx.read_result(), rt.ctx.counters()))
-        rt.close()
+IMG = np.load(os.path.join(HERE, "golden", "oracle_images.npz"))
+TRAV = {"reference": abi.TRAVERSAL_REFERENCE, "fast": abi.TRAVERSAL_FAST}
+
+
+def gpu_render(desc, w, h, frames=1, traversal=abi.TRAVERSAL_FAST, max_bounces=1, counters=True):
+    rt, sc, res = scenes.instantiate(desc, w, h)
+    rt.ctx.set_option(abi.OPT_COUNTERS, int(counters))
+    rt.ctx.set_option(abi.OPT_MAX_BOUNCES, max_bounces)
+    rt.ctx.set_option(abi.OPT_TRAVERSAL, traversal)
+    for _ in range(frames):
+        rt.render()
+    out = rt.ctx.read_accum(), rt.ctx.read_result(), rt.ctx.counters()
+    rt.close()
     return out
 
 
-def test_config1_spheres_reference_order(oracle):
-    (ga, gr, gc), (ca, cr, cc) = render_both(oracle, scenes.test_scene_spheres(), 256, 256)
-    frac, rmse, nanmm, _ = compare_accum(ga, ca)
-    assert frac >= 0.995 and rmse <= 0.02 and nanmm <= 1e-5, (frac, rmse, nanmm)
-    assert gc["pixels"] == cc["pixels"] == 256 * 256
-    assert abs(gc["segments"] - cc["segments"]) <= 4
+def cpu_render(oracle, desc, w, h, frames=1, max_bounces=1):
+    rt, sc, res = oracle.instantiate(desc, w, h)
+    rt.ctx.set_option(abi.OPT_COUNTERS, 1)
+    rt.ctx.set_option(abi.OPT_MAX_BOUNCES, max_bounces)
+    for _ in range(frames):
+        rt.render()
+    out = rt.ctx.read_accum(), rt.ctx.read_result(), rt.ctx.counters()
+    rt.close()
+    return out
 
 
-def test_small_mesh_scene_reference_order_counters_match(oracle):
-    desc = scenes.small_mesh_scene(with_lights=True)
-    (ga, gr, gc), (ca, cr, cc) = render_both(oracle, desc, 160, 90)
+def assert_1spp(ga, ca):
     frac, rmse, nanmm, _ = compare_accum(ga, ca)
     assert frac >= 0.995 and rmse <= 0.02 and nanmm <= 1e-5, (frac, rmse, nanmm)
-    # identical visit order: the traversal counters agree up to the handful of flipped paths
-    for k in ("n_oct", "n_mesh", "n_node", "n_tri", "mesh_hits", "tex_taps"):
-        assert abs(gc[k] - cc[k]) <= 0.002 * max(cc[k], 1) + 8, (k, gc[k], cc[k])
+
+
+@pytest.mark.parametrize("trav", ["reference", "fast"])
+def test_config1_spheres_256(oracle, trav):
+    desc = scenes.test_scene_spheres()
+    ga, gr, gc = gpu_render(desc, 256, 256, traversal=TRAV[trav])
+    ca, cr, cc = cpu_render(oracle, desc, 256, 256)
+    assert_1spp(ga, ca)
+    assert gc["pixels"] == cc["pixels"] == 256 * 256  # all 256 rows are rendered (the reference would stop at 252: Q15)
+    assert abs(gc["segments"] - cc["segments"]) <= 4 and abs(gc["sphere_hits"] - cc["sphere_hits"]) <= 4
     assert (np.abs(gr.astype(int) - cr.astype(int)) > 1).mean() < 0.005
 
 
-def test_fast_traversal_matches_oracle_small_scene(oracle):
+def test_reference_order_counters_equal_the_oracles(oracle):
+    """Identical visit order: bbCheckCount / triCheckCount sums agree up to the handful of flipped paths. These
+    counters are the roofline numerator of bench.py."""
     desc = scenes.small_mesh_scene(with_lights=True)
-    (ga, gr, gc), (ca, cr, cc) = render_both(oracle, desc, 160, 90, traversal=abi.TRAVERSAL_FAST)
-    frac, rmse, nanmm, _ = compare_accum(ga, ca)
-    assert frac >= 0.995 and rmse <= 0.02 and nanmm <= 1e-5, (frac, rmse, nanmm)
-    for k in ("pixels", "segments", "mesh_hits", "sphere_hits", "tex_taps", "env_taps"):
+    ga, gr, gc = gpu_render(desc, 160, 90, traversal=abi.TRAVERSAL_REFERENCE)
+    ca, cr, cc = cpu_render(oracle, desc, 160, 90)
+    assert_1spp(ga, ca)
+    for k in ("n_oct", "n_mesh", "n_node", "n_tri", "mesh_hits", "tex_taps", "env_taps", "segments"):
         assert abs(gc[k] - cc[k]) <= 0.002 * max(cc[k], 1) + 8, (k, gc[k], cc[k])
 
 
-def test_fast_equals_reference_order_on_gpu():
-    """Same device, same libm: the two traversals must agree bit for bit except equal-distance ties."""
+@pytest.mark.parametrize("name", sorted(make_golden.golden_scenes()))
+@pytest.mark.parametrize("trav", ["reference", "fast"])
+def test_golden_images(name, trav):
+    desc, w, h, frames, mb = make_golden.golden_scenes()[name]
+    ga, gr, gc = gpu_render(desc, w, h, frames=frames, traversal=TRAV[trav], max_bounces=mb)
+    gold = IMG[name]
+    frac, rmse, nanmm, l2 = compare_accum(ga, gold, frames)
+    # 64x36 images: allow a few more flipped pixels than the 0.5 % of the large-image rule (>= 99 %)
+    assert frac >= 0.99 and rmse <= 0.02 and nanmm <= 1e-3, (name, frac, rmse, nanmm)
+    assert (ga[..., 3] == frames).all()
+    gcnt = dict(zip(sorted(gc), IMG[name + "_counters"].tolist()))
+    assert gc["pixels"] == gcnt["pixels"]
+    assert abs(gc["segments"] - gcnt["segments"]) <= 0.003 * gcnt["segments"] + 4
+    if trav == "reference":
+        assert abs(gc["n_node"] - gcnt["n_node"]) <= 0.003 * gcnt["n_node"] + 16
+
+
+@pytest.mark.parametrize("scene", ["dragon", "sponza", "glass", "transforms"])
+def test_fast_traversal_vs_oracle(oracle, scene):
+    if scene == "dragon":
+        desc, mb = scenes.dragon_proxy(80000), 1
+    elif scene == "sponza":
+        desc, mb = scenes.sponza_proxy(tex_size=64, env_face=64, tri_scale=0.25), 1
+    elif scene == "glass":
+        desc, mb = scenes.glass_revolver_proxy(tex_size=128, env_face=64, detail=0.5), 8  # Q23: reported at 8 bounces too
+    else:
+        desc, mb = scenes.small_mesh_scene(seed=13, n_objects=7, detail=12, transforms=True, with_lights=True), 1
+    w, h = 320, 180
+    ga, gr, gc = gpu_render(desc, w, h, max_bounces=mb)
+    ca, cr, cc = cpu_render(oracle, desc, w, h, max_bounces=mb)
+    if scene == "transforms":
+        # rotated instances are baked to world space: distances agree to rounding, not to the bit -> a few more
+        # grazing-edge flips than with identity instances
+        frac, rmse, nanmm, _ = compare_accum(ga, ca)
+        assert frac >= 0.99 and rmse <= 0.03, (frac, rmse)
+    else:
+        assert_1spp(ga, ca)
+    for k in ("pixels", "segments", "mesh_hits", "sphere_hits", "tex_taps", "env_taps"):
+        assert abs(gc[k] - cc[k]) <= 0.004 * max(cc[k], 1) + 8, (k, gc[k], cc[k])
+
+
+def test_fast_equals_reference_order_bit_for_bit():
+    """Same device, same libm, identity instances: the two traversals agree to the bit except equal-distance ties."""
     desc = scenes.small_mesh_scene(seed=5, n_objects=8, detail=16, with_lights=False)
-    accs = []
-    for trav in (abi.TRAVERSAL_REFERENCE, abi.TRAVERSAL_FAST):
-        rt, _, _ = scenes.instantiate(desc, 320, 180)
-        rt.ctx.set_option(abi.OPT_TRAVERSAL, trav)
-        for _ in range(2):
-            rt.render()
-        accs.append(rt.ctx.read_accum())
-        rt.close()
+    accs = [gpu_render(desc, 320, 180, frames=2, traversal=t)[0] for t in (abi.TRAVERSAL_REFERENCE, abi.TRAVERSAL_FAST)]
     same = (accs[0] == accs[1]).all(-1) | (np.isnan(accs[0]).any(-1) & np.isnan(accs[1]).any(-1))
     assert same.mean() >= 0.999, same.mean()
+
+
+def test_progressive_accumulation_256spp(oracle):
+    desc = scenes.small_mesh_scene(seed=9, with_lights=False)
+    w, h, n = 64, 36, 256
+    ga, gr, gc = gpu_render(desc, w, h, frames=n, counters=False)
+    ca, cr, cc = cpu_render(oracle, desc, w, h, frames=n)
+    g, c = ga[..., :3] / n, ca[..., :3] / n
+    fin = np.isfinite(g).all(-1) & np.isfinite(c).all(-1)
+    l2 = np.sqrt(((g - c) ** 2).sum(-1))
+    assert (l2[fin] <= 4 / 255).mean() >= 0.999
+    assert np.sqrt(((g - c)[fin] ** 2).mean()) <= 1 / 255
+    assert (ga[..., 3] == n).all()
+    assert (np.abs(gr.astype(int) - cr.astype(int)) > 2).mean() < 0.01  # resolved RGBA8 = saturate(acc / N)
+
+
+def test_debug_heat_maps(oracle):
+    """debugMode 1/2 show the REFERENCE traversal's box / triangle check counts (RaytracerCS.hlsl:516-520); the
+    fast path hands those frames to the reference-order kernel."""
+    desc = scenes.small_mesh_scene(seed=3, with_lights=False)
+    for mode in (1, 2):
+        rt, sc, res = scenes.instantiate(desc, 96, 54)
+        rt.setDebugMode(mode, 60)
+        rt.render()
+        g = rt.ctx.read_accum()
+        rt.close()
+        ort, _, _ = oracle.instantiate(desc, 96, 54)
+        ort.setDebugMode(mode, 60)
+        ort.render()
+        c = ort.ctx.read_accum()
+        ort.close()
+        assert (np.abs(g - c).max(-1) < 1e-6).mean() > 0.995
+        assert ((g[..., 0] == 1) & (g[..., 1] == 0)).any() or mode == 2  # some pixels exceed the cap -> red
+
+
+def test_scale_texture_is_bit_exact_with_the_oracle(oracle):
+    rng = np.random.default_rng(8)
+    src = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    gctx = host.Context()
+    octx = oracle.context()
+    for (w, h) in [(16, 16), (64, 64), (53, 37), (7, 91)]:
+        assert np.array_equal(gctx.scale_texture(src, w, h), octx.scale_texture(src, w, h))
+    gctx.close(); octx.close()

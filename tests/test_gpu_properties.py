@@ -1,0 +1,183 @@
+"""GPU tests at BASELINE.json's full sizes through size-independent properties (the oracle would take minutes
+there), plus the boundary's error behaviour and edge cases."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import abi, host, scenes
+
+pytestmark = pytest.mark.gpu
+tiling = importlib.import_module("gpu-raytracer_amd.tiling")
+
+
+@pytest.fixture(scope="module")
+def sponza():
+    desc = scenes.sponza_proxy()
+    assert desc.num_triangles == scenes.SPONZA_TRIANGLES and len(desc.meshes) == scenes.SPONZA_MESHES and len(desc.textures) == scenes.SPONZA_TEXTURES
+    rt, sc, res = scenes.instantiate(desc, 1920, 1080)
+    yield rt
+    rt.close()
+
+
+def test_sponza_1080p_fast_equals_reference_order(sponza):
+    rt = sponza
+    accs = []
+    for trav in (abi.TRAVERSAL_FAST, abi.TRAVERSAL_REFERENCE):
+        rt.ctx.set_option(abi.OPT_TRAVERSAL, trav)
+        rt.resetAccumulation()
+        rt.render()
+        accs.append(rt.ctx.read_accum())
+    rt.ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST)
+    same = (accs[0] == accs[1]).all(-1) | (np.isnan(accs[0]).any(-1) & np.isnan(accs[1]).any(-1))
+    assert same.mean() >= 0.9995, same.mean()  # ties only: 390 meshes share many coincident edges
+    l2 = np.sqrt(((accs[0][..., :3] - accs[1][..., :3]) ** 2).sum(-1))
+    assert (l2[np.isfinite(l2)] <= 1e-3).mean() >= 0.9999
+
+
+def test_sponza_1080p_accumulation_is_a_running_sum(sponza):
+    """acc after frames 1..3 == sum of the three frames rendered alone (same frame indices); alpha counts frames."""
+    rt = sponza
+    rt.resetAccumulation()
+    for _ in range(3):
+        rt.render()
+    acc3 = rt.ctx.read_accum()
+    assert (acc3[..., 3] == 3).all()
+    total = np.zeros_like(acc3)
+    rd = rt.render_data
+    for n in (1, 2, 3):
+        rt.ctx.reset_accumulation()
+        rd.numAccumulationFrames = n
+        rt.ctx.render(rd)
+        frame = rt.ctx.read_accum()
+        total = (total + frame).astype(np.float32)  # (a+b)+c in float32, the order the kernel adds in
+    fin = np.isfinite(acc3).all(-1)
+    assert np.array_equal(acc3[fin], total[fin])
+    res = rt.ctx.read_result()
+    assert res.shape == (1080, 1920, 4) and (res[..., 3] > 0).all()
+
+
+def test_sponza_1080p_tile_split_is_bit_identical(sponza):
+    """Rows rendered by a context that owns every other 8-row stripe equal the same rows of the full frame."""
+    rt = sponza
+    rt.resetAccumulation()
+    rt.render()
+    full = rt.ctx.read_accum()
+    rd = rt.render_data
+    tiles = []
+    for r in range(2):
+        rt.ctx.set_tile(8, r, 2)
+        rt.ctx.render(rd)  # same frame index
+        tiles.append(rt.ctx.read_accum())
+    rt.ctx.set_tile(1080, 0, 1)
+    merged = tiling.deinterleave(tiles, 1080, 8)
+    assert np.array_equal(merged, full, equal_nan=True)
+
+
+def test_sponza_1080p_rays_per_frame_and_timing(sponza):
+    rt = sponza
+    rt.resetAccumulation()
+    rt.ctx.reset_counters()
+    rt.ctx.set_option(abi.OPT_TIMING, 4)
+    for _ in range(4):
+        rt.render()
+    trace, shade, other, frames = rt.ctx.stage_ms()
+    rt.ctx.set_option(abi.OPT_TIMING, 0)
+    c = rt.ctx.counters()
+    assert frames == 4 and c["pixels"] == 4 * 1920 * 1080
+    assert 1920 * 1080 * 4 < c["segments"] <= 2 * 1920 * 1080 * 4  # NUM_BOUNCES = 1: at most 2 segments per sample
+    assert 0 < trace < 100 and 0 < shade < 100 and abs(other) < 5
+
+
+def test_dragon_871k_fast_equals_reference_order():
+    desc = scenes.dragon_proxy(871414)
+    assert desc.num_triangles == 871416  # + the 2-triangle ground quad
+    rt, sc, res = scenes.instantiate(desc, 1280, 720)
+    accs = []
+    for trav in (abi.TRAVERSAL_FAST, abi.TRAVERSAL_REFERENCE):
+        rt.ctx.set_option(abi.OPT_TRAVERSAL, trav)
+        rt.resetAccumulation()
+        rt.render()
+        accs.append(rt.ctx.read_accum())
+    rt.close()
+    same = (accs[0] == accs[1]).all(-1) | (np.isnan(accs[0]).any(-1) & np.isnan(accs[1]).any(-1))
+    assert same.mean() >= 0.999, same.mean()
+
+
+# ---- boundary behaviour ---------------------------------------------------------------------------------------
+def test_error_codes_and_messages():
+    ctx = host.Context()
+    rd = abi.RenderData()
+    rd.textureDims[0], rd.textureDims[1] = 8, 8
+    assert ctx.fns.render(ctx.h, C.byref(rd)) == -4  # OKRT_ERR_STATE: render before resize
+    assert b"resize" in ctx.fns.last_error(ctx.h)
+    ctx.resize(8, 8)
+    tri = np.zeros((2, 9), np.float32)
+    assert ctx.set_table_raw(abi.TABLE_TRI_POS, tri, 40, 2) == -1  # wrong element stride
+    assert b"stride" in ctx.fns.last_error(ctx.h)
+    assert ctx.fns.set_table(ctx.h, 3, None, 4, 0) == -1  # slot 3 is an image, not a table
+    rd.numSpheres = 2
+    assert ctx.fns.render(ctx.h, C.byref(rd)) == -5  # OKRT_ERR_RANGE: count exceeds the uploaded table
+    rd.numSpheres = 0
+    rd.textureDims[0] = 9
+    assert ctx.fns.render(ctx.h, C.byref(rd)) == -1  # textureDims must match the framebuffer
+    rd.textureDims[0] = 8
+    # a BVH whose child index points backwards (a cycle) must be refused, not traversed
+    ctx.set_table(abi.TABLE_TRI_POS, tri)
+    ctx.set_table(abi.TABLE_TRI_INFO, np.zeros((2, 33), np.float32))
+    bad = np.zeros((3, 9), np.uint32); bad[0, 8] = 0  # node 0 -> children 0,1
+    bad[1:, 8] = 0xFFFFFFFF
+    ctx.set_table(abi.TABLE_BVH, bad)
+    assert ctx.fns.render(ctx.h, C.byref(rd)) == -5
+    assert b"BVH node 0" in ctx.fns.last_error(ctx.h)
+    good = bad.copy(); good[0, 8] = 1; good[1, 6:8] = [0, 1]; good[2, 6:8] = [1, 5]  # leaf range beyond t0
+    ctx.set_table(abi.TABLE_BVH, good)
+    assert ctx.fns.render(ctx.h, C.byref(rd)) == -5
+    good[2, 6:8] = [1, 2]
+    ctx.set_table(abi.TABLE_BVH, good)
+    assert ctx.fns.render(ctx.h, C.byref(rd)) == 0  # valid again (no octree -> nothing to hit)
+    assert ctx.fns.set_option(ctx.h, 99, 0) == -1
+    assert ctx.fns.set_tile(ctx.h, 0, 0, 1) == -1 and ctx.fns.set_tile(ctx.h, 4, 2, 2) == -1
+    ctx.close()
+    h = C.c_void_p()
+    assert ctx.fns.create(9999, C.byref(h)) == -2 and not h.value  # no such device
+
+
+def test_empty_scene_renders_the_environment_only():
+    ctx = host.Context()
+    ctx.resize(33, 17)  # not a multiple of any tile size: every pixel is still covered (Q15)
+    faces = np.zeros((6, 4, 4, 4), np.uint8); faces[..., 0] = 255
+    ctx.set_envmap(faces)
+    rd = abi.RenderData()
+    rd.accumulationEnabled = 1; rd.numAccumulationFrames = 1
+    rd.textureDims[0], rd.textureDims[1] = 33, 17
+    for i in range(16):
+        rd.cameraInverseProjectionMatrix[i] = rd.cameraInverseViewMatrix[i] = float(i % 5 == 0)
+    rd.cameraNearZ = 0.1
+    for trav in (abi.TRAVERSAL_FAST, abi.TRAVERSAL_REFERENCE):
+        ctx.set_option(abi.OPT_TRAVERSAL, trav)
+        ctx.reset_accumulation()
+        ctx.render(rd)
+        acc = ctx.read_accum()
+        assert acc.shape == (17, 33, 4) and np.allclose(acc[..., 0], 1.0) and (acc[..., 1:3] == 0).all() and (acc[..., 3] == 1).all()
+    ctx.set_envmap(None)  # unbound cube: black
+    ctx.reset_accumulation(); ctx.render(rd)
+    assert (ctx.read_accum()[..., :3] == 0).all()
+    ctx.close()
+
+
+def test_table_update_with_a_different_count_reallocates():
+    """GPUStorage::update grows/shrinks with the count (GPUStorage.h:36-37)."""
+    desc = scenes.small_mesh_scene(seed=3, n_objects=3, detail=5, with_textures=False)
+    rt, sc, res = scenes.instantiate(desc, 64, 36)
+    rt.render()
+    a = rt.ctx.read_accum()
+    rt.loadMeshAndBvhData(8, 2)   # "Rebuild BVH tree" (Application.cpp:408-411): different node count, same image
+    rt.createOctTree(sc, 1, 1)
+    rt.resetAccumulation()
+    rt.render()
+    b = rt.ctx.read_accum()
+    same = (a == b).all(-1)
+    assert same.mean() > 0.995
+    rt.close()
