@@ -488,7 +488,7 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
     return s
 
 
-def small_mesh_scene(seed=3, n_objects=6, detail=10, with_textures=True, with_lights=False, transforms=False, tex_size=32):
+def small_mesh_scene(seed=3, n_objects=6, detail=10, with_textures=True, with_lights=False, transforms=False, tex_size=32, octree=(2, 2)):
     """A tiny mixed scene for parity tests: blobs, a glass ball, a floor, spheres, optional lights."""
     rng = np.random.default_rng(seed)
     s = SceneDescription(f"small-{seed}")
@@ -531,7 +531,7 @@ def small_mesh_scene(seed=3, n_objects=6, detail=10, with_textures=True, with_li
         s.dir_lights = [((35.0, 20.0, 0.0), (1.0, 1.0, 0.9), 0.5, 30.0)]
     s.env_cross = sky_cross(16)
     s.camera = dict(position=(0.0, 3.0, -18.0), rotation=(6.0, 0.0, 0.0), fov=80.0, near_z=0.1, far_z=1000.0)
-    s.octree = (2, 2)
+    s.octree = octree
     return s
 
 

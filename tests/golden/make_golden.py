@@ -30,7 +30,10 @@ def golden_scenes():
         "spheres": (scenes.test_scene_spheres(), 64, 64, 1, 1),
         "small_lights": (scenes.small_mesh_scene(with_lights=True), 64, 36, 1, 1),
         "small_16spp": (scenes.small_mesh_scene(seed=9, with_lights=False), 64, 36, 16, 1),
-        "small_transforms": (scenes.small_mesh_scene(seed=4, transforms=True), 64, 36, 1, 1),
+        # rotated + translated instances; root-only octree: the reference refits octree CHILD boxes to the
+        # LOCAL mesh boxes (quirk Q22, RayTracer.cpp:562), which wrongly culls moved meshes, so only the root
+        # (built from transformed corners, :546-560) bounds them correctly
+        "small_transforms": (scenes.small_mesh_scene(seed=4, transforms=True, octree=(0, 50)), 64, 36, 1, 1),
         "glass_b4": (scenes.glass_revolver_proxy(tex_size=64, env_face=32, detail=0.2), 64, 36, 1, 4),
         "dragon2k": (scenes.dragon_proxy(2000), 64, 36, 1, 1),
         "sponza_tiny": (scenes.sponza_proxy(tex_size=32, env_face=16, tri_scale=0.02), 64, 36, 1, 1),
