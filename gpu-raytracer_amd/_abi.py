@@ -114,7 +114,8 @@ def bind(lib, prefix, extra=None):
 
 
 def device_library_path():
-    return os.path.join(PKG_DIR, "libokrt.so")
+    # OKRT_LIBRARY: developer override to A/B another build of the same ABI
+    return os.environ.get("OKRT_LIBRARY") or os.path.join(PKG_DIR, "libokrt.so")
 
 
 _device = None

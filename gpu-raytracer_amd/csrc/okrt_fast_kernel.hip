@@ -11,9 +11,13 @@
 //   traceKernel<QUEUED> / shadeKernel<NEXT>   ... one pair per further segment
 //
 // Traversal (what the profile is dominated by) is built for CDNA4:
-//   * wave64, 256-thread blocks, persistent: each wave pulls rays from a global cursor and REFILLS
-//     idle lanes when fewer than kRefillBelow lanes are still traversing (ballot + mbcnt ranks,
-//     one atomic per refill), so divergence in path length does not idle the SIMD;
+//   * wave64, 256-thread blocks, persistent: each wave REFILLS its idle lanes when fewer than
+//     kRefillBelow lanes are still traversing (ballot + prefix-popcount ranks), so divergence in path
+//     length does not idle the SIMD. Rays come from kShards = 8 queue shards, one per XCD (a
+//     contiguous band of the image for camera rays): a wave reserves kBatch rays at a time from its
+//     own XCD's cursor (HW_REG_XCC_ID) and steals from the other shards when it runs dry. One shared
+//     cursor word saturates at ~90 atomics/us on MI355X and WAS the bottleneck of the first version;
+//     sharding + batching removes it and keeps each XCD's L2 on one region of the scene;
 //   * per-lane traversal stack in LDS ([entry][thread], conflict-free), entries carry the child's
 //     entry distance so stale entries are dropped without touching memory; deeper levels spill to
 //     a per-thread HBM slab (sized from the tree depth at build time);
@@ -24,6 +28,8 @@
 //     shader's edge convention, hit distance = length(dir*t) (RaytracerCS.hlsl:276,285,306-316),
 //     so for identity instances (all benchmark scenes) the closest hit equals the reference's bit
 //     for bit; only equal-distance ties may resolve to a different triangle.
+#include <cstdlib>
+
 #include "okrt_fast.h"
 
 namespace okrt {
@@ -34,6 +40,23 @@ constexpr int kTraceThreads = 256;
 constexpr int kLdsStack = 12;        // entries per lane kept in LDS
 constexpr int kRefillBelow = 40;     // refill idle lanes when fewer than this many lanes are active
 constexpr uint32_t kDone = kEmptyRef;
+constexpr uint32_t kShards = 8;      // queue shards = XCDs
+constexpr uint32_t kBatch = 64;      // rays a wave reserves per cursor atomic (sweep: 64 best with 5 blocks/CU)
+constexpr uint32_t kCursorStride = 32;  // words: one cursor per 128-byte line (device-scope atomics serialise per line)
+
+// A sharded queue: shard s owns positions [s*cap, s*cap + count(s)). Camera rays: count(s) follows
+// from `total`; queued rays: counts[] written by the shading kernel. cursors[] = next unreserved.
+struct ShardView {
+    uint32_t cap, total;
+    uint32_t batch, xcdAffinity, refillBelow;  // tunables (developer knobs: OKRT_FAST_BATCH / _AFFINITY / _REFILL)
+    const uint32_t* counts;  // nullptr for camera rays
+    uint32_t* cursors;       // cursors[s * kCursorStride]
+    __device__ uint32_t count(uint32_t s) const {
+        if (counts) return counts[s];
+        const uint32_t lo = s * cap;
+        return total > lo ? min(total - lo, cap) : 0u;
+    }
+};
 
 struct RayQueue {        // SoA, capacity = owned pixels
     float4* a;           // origin.xyz, dir.x
@@ -64,18 +87,25 @@ OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t
 
 template <bool PRIMARY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
-                                                            HitBuffer hb, const uint32_t* qCount, uint32_t* cursor,
-                                                            unsigned long long* counters, unsigned long long* rayTotals) {
+                                                            HitBuffer hb, ShardView sv, unsigned long long* counters,
+                                                            unsigned long long* rayTotals) {
     __shared__ uint32_t sRef[kLdsStack][kTraceThreads];
     __shared__ float sDist[kLdsStack][kTraceThreads];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     uint2* myOverflow = fv.overflow + (size_t)(blockIdx.x * kTraceThreads + tid) * fv.overflowCap;
-    const uint32_t total = PRIMARY ? (((tile.W + 7) >> 3) * ((tile.rows + 7) >> 3)) << 6 : *qCount;
     if (!COUNT && blockIdx.x == 0 && tid == 0) {  // rays of this launch, always counted (okrt_counters.pixels / .segments)
-        const unsigned long long n = PRIMARY ? (unsigned long long)tile.W * tile.rows : (unsigned long long)total;
+        unsigned long long n = 0;
+        if (PRIMARY) n = (unsigned long long)tile.W * tile.rows;
+        else for (uint32_t k = 0; k < kShards; ++k) n += sv.count(k);
         if (PRIMARY) atomicAdd(&rayTotals[0], n);
         atomicAdd(&rayTotals[1], n);
     }
+    // wave-uniform work-fetch state
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t shard = sv.xcdAffinity ? (xcc & (kShards - 1)) : 0u, tried = 0, resNext = 0, resEnd = 0;
+    uint32_t preRaw = 0, preShard = 0;  // prefetched reservation: preRaw is only meaningful in lane 0
+    bool havePre = false;
 
     uint32_t rayIdx = kInvalid;   // the ray this lane is tracing
     uint32_t cur = kDone;         // node/leaf reference being processed, kDone = lane idle
@@ -86,66 +116,155 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
     uint32_t nNodes = 0, nTris = 0, nSeg = 0;
     bool exhausted = false;
 
+#ifdef OKRT_STAMPS
+    unsigned long long tRefill = 0, tInner = 0, tLeaf = 0, tStart = __builtin_amdgcn_s_memtime(), nRefill = 0, nIter = 0, laneIters = 0;
+#define OKRT_T0 unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#define OKRT_T1(acc) acc += __builtin_amdgcn_s_memtime() - t0_;
+#else
+#define OKRT_T0
+#define OKRT_T1(acc)
+#endif
     for (;;) {
+#ifdef OKRT_STAMPS
+        nIter++;
+        laneIters += __popcll(__ballot(cur != kDone));
+#endif
         // ---- refill: lanes whose traversal ended store their hit and take the next rays --------
         const unsigned long long idle = __ballot(cur == kDone);
-        if (__popcll(~idle) < kRefillBelow) {
+        if ((uint32_t)__popcll(~idle) < sv.refillBelow) {
+            OKRT_T0
+#ifdef OKRT_STAMPS
+            nRefill++;
+#endif
             if (cur == kDone && rayIdx != kInvalid) {
                 hb.h[rayIdx] = make_float4(best, hbu, hbv, __uint_as_float(hitIdx));
                 hb.tri[rayIdx] = hitTri;
                 rayIdx = kInvalid;
             }
-            if (!exhausted) {  // wave-uniform
-                bool sawEnd = false;
-                if (cur == kDone) {
-                    const uint32_t want = (uint32_t)__popcll(idle);
-                    uint32_t base = 0;
-                    const int leader = __ffsll((long long)idle) - 1;
-                    if ((int)lane == leader) base = atomicAdd(cursor, want);
-                    base = __shfl(base, leader, 64);
-                    const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    sawEnd = mine >= total;
-                    if (!sawEnd) {
-                        bool valid = true;
-                        Ray ray;
-                        if (PRIMARY) {
+            if (PRIMARY && sv.xcdAffinity == 2) {  // A/B: the first version's fetch (one shared cursor, one atomic per refill)
+                if (!exhausted) {
+                    bool sawEnd = false;
+                    if (cur == kDone) {
+                        const unsigned long long idle2 = __ballot(cur == kDone);
+                        const uint32_t want = (uint32_t)__popcll(idle2);
+                        uint32_t base = 0;
+                        const int leader = __ffsll((long long)idle2) - 1;
+                        if ((int)lane == leader) base = atomicAdd(&sv.cursors[0], want);
+                        base = __shfl(base, leader, 64);
+                        const uint32_t mine = base + (uint32_t)__popcll(idle2 & ((1ull << lane) - 1ull));
+                        sawEnd = mine >= sv.total;
+                        if (!sawEnd) {
                             uint32_t px, lrow, seed;
-                            valid = primaryPixel(tile, mine, px, lrow);
-                            if (valid) ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
-                        } else {
-                            float4 A = q.a[mine], B = q.b[mine];
-                            ray.origin = mk(A.x, A.y, A.z);
-                            ray.direction = mk(A.w, B.x, B.y);
-                        }
-                        if (valid) {
-                            rayIdx = mine;
-                            nSeg++;
-                            ro = ray.origin;
-                            // the shader re-normalises the direction per instance (RaytracerCS.hlsl:276)
-                            rdir = normalize(ray.direction);
-                            inv = rcp3(rdir);
-                            best = kFltMax;
-                            hitIdx = kInvalid;
-                            hitTri = kInvalid;
-                            hbu = hbv = 0.f;
-                            for (uint32_t i = 0; i < rd.numSpheres; i++) {  // RaytracerCS.hlsl:232-242 (original direction)
-                                float d = rayAndSphere(ray, ld3(s.spheres[i].position), s.spheres[i].radius);
-                                if (d > 0.f && d < best) {
-                                    best = d;
-                                    hitIdx = i;
-                                }
+                            if (primaryPixel(tile, mine, px, lrow)) {
+                                Ray ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
+                                rayIdx = mine;
+                                nSeg++;
+                                ro = ray.origin;
+                                rdir = normalize(ray.direction);
+                                inv = rcp3(rdir);
+                                best = kFltMax;
+                                hitIdx = kInvalid;
+                                hitTri = kInvalid;
+                                hbu = hbv = 0.f;
+                                sp = 0;
+                                cur = 0;
                             }
-                            sp = 0;
-                            cur = 0;  // root node
                         }
                     }
+                    exhausted = __ballot(sawEnd) != 0ull;
                 }
-                exhausted = __ballot(sawEnd) != 0ull;
+            } else
+            for (int round = 0; round < 2 && !exhausted; ++round) {
+                const unsigned long long need = __ballot(cur == kDone);
+                if (!need) break;
+                if (resNext == resEnd) {  // take the prefetched reservation (wave-uniform); steal when a shard is dry
+                    while (tried < kShards) {
+                        if (!havePre) {
+                            if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], sv.batch ? sv.batch : (uint32_t)__popcll(need));
+                            preShard = shard;
+                            havePre = true;
+                        }
+                        const uint32_t bpos = __builtin_amdgcn_readfirstlane(preRaw);  // waits for the atomic here
+                        const uint32_t cnt = sv.count(preShard);
+                        havePre = false;
+                        if (bpos < cnt) {
+                            resNext = preShard * sv.cap + bpos;
+                            resEnd = preShard * sv.cap + min(bpos + (sv.batch ? sv.batch : (uint32_t)__popcll(need)), cnt);
+                            tried = 0;
+                            break;
+                        }
+                        // this shard is dry: look at all cursors with ONE load (lane k reads shard k) and jump to the
+                        // next shard that still has rays, instead of probing each with a returning atomic
+                        uint32_t seen = 0xFFFFFFFFu, lim = 0;
+                        if (lane < kShards) {
+                            seen = __hip_atomic_load(&sv.cursors[lane * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            lim = sv.count(lane);
+                        }
+                        const uint32_t live = (uint32_t)__ballot(seen < lim) & ((1u << kShards) - 1u);
+                        if (!live) {
+                            tried = kShards;
+                            break;
+                        }
+                        const uint32_t rot = ((live >> shard) | (live << (kShards - shard))) & ((1u << kShards) - 1u);  // bit j = shard+j
+                        shard = (shard + (uint32_t)__builtin_ctz(rot)) & (kShards - 1);
+                        tried++;
+                    }
+                    if (resNext == resEnd) {
+                        exhausted = true;
+                        break;
+                    }
+                    if (sv.batch) {  // issue the NEXT reservation now; its round trip overlaps the traversal of this batch
+                        if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], sv.batch);
+                        preShard = shard;
+                        havePre = true;
+                    }
+                }
+                const uint32_t avail = resEnd - resNext;
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (cur == kDone && rank < avail) {
+                    const uint32_t mine = resNext + rank;
+                    bool valid = true;
+                    Ray ray;
+                    if (PRIMARY) {
+                        uint32_t px, lrow, seed;
+                        valid = primaryPixel(tile, mine, px, lrow);
+                        if (valid) ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
+                    } else {
+                        float4 A = q.a[mine], B = q.b[mine];
+                        ray.origin = mk(A.x, A.y, A.z);
+                        ray.direction = mk(A.w, B.x, B.y);
+                    }
+                    if (valid) {
+                        rayIdx = mine;
+                        nSeg++;
+                        ro = ray.origin;
+                        // the shader re-normalises the direction per instance (RaytracerCS.hlsl:276)
+                        rdir = normalize(ray.direction);
+                        inv = rcp3(rdir);
+                        best = kFltMax;
+                        hitIdx = kInvalid;
+                        hitTri = kInvalid;
+                        hbu = hbv = 0.f;
+                        for (uint32_t i = 0; i < rd.numSpheres; i++) {  // RaytracerCS.hlsl:232-242 (original direction)
+                            float d = rayAndSphere(ray, ld3(s.spheres[i].position), s.spheres[i].radius);
+                            if (d > 0.f && d < best) {
+                                best = d;
+                                hitIdx = i;
+                            }
+                        }
+                        sp = 0;
+                        cur = 0;  // root node
+                    }
+                }
+                resNext += min((uint32_t)__popcll(need), avail);
             }
-            if (__ballot(rayIdx != kInvalid) == 0ull) break;  // queue drained and every lane idle
+            OKRT_T1(tRefill)
+            if (__ballot(rayIdx != kInvalid) == 0ull) break;  // queues drained and every lane idle
         }
 
         // ---- inner nodes: descend nearest-first -------------------------------------------------
+        {
+        OKRT_T0
         while (cur != kDone && !(cur & kLeafBit)) {
             const float4* np = fv.nodes + (size_t)cur * 8;
             const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
@@ -212,7 +331,11 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
             }
         }
 
+        OKRT_T1(tInner)
+        }
+
         // ---- leaf: Moeller-Trumbore on its triangles -------------------------------------------------
+        OKRT_T0
         if (cur != kDone) {
             const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
             for (uint32_t j = 0; j < count; ++j) {
@@ -251,8 +374,16 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                 }
             }
         }
+        OKRT_T1(tLeaf)
     }
 
+#ifdef OKRT_STAMPS
+    if (COUNT && counters && lane == 0) {  // cycle sums per wave: n_oct=refill, n_mesh=inner, n_node=leaf, n_tri=total, mesh_hits=#refills, sphere_hits=#iters, tex_taps=active lane-iters
+        atomicAdd(&counters[2], tRefill); atomicAdd(&counters[3], tInner); atomicAdd(&counters[4], tLeaf);
+        atomicAdd(&counters[5], __builtin_amdgcn_s_memtime() - tStart);
+        atomicAdd(&counters[6], nRefill); atomicAdd(&counters[7], nIter); atomicAdd(&counters[8], laneIters);
+    }
+#endif
     if (COUNT && counters) {
         uint32_t vals[3] = {nSeg, nNodes, nTris};
         const int slot[3] = {1, 10, 11};  // segments, fast_nodes, fast_tris
@@ -269,10 +400,12 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
 // Finished paths (miss, or last segment) accumulate; the rest are compacted into `qOut`.
 template <bool FIRST, bool COUNT>
 __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data rd, TileView tile, RayQueue qIn, HitBuffer hb,
-                                                  const uint32_t* inCount, RayQueue qOut, uint32_t* outCount, uint32_t bounce,
+                                                  ShardView in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce,
                                                   uint32_t lastBounce, float4* accum, uint32_t* result, unsigned long long* counters) {
+    // positions are [shard][cap]; cap is a multiple of 256, so a block (and a wave) never straddles shards
     const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    const uint32_t total = FIRST ? (((tile.W + 7) >> 3) * ((tile.rows + 7) >> 3)) << 6 : *inCount;
+    const uint32_t shard = (blockIdx.x * 256) / in.cap;
+    const uint32_t total = shard * in.cap + in.count(shard);
     PathCounters cnt = {};
     bool alive = false;  // continues into the next segment
     Ray ray;
@@ -322,10 +455,10 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
     if (m) {
         uint32_t base = 0;
         const int leader = __ffsll((long long)m) - 1;
-        if ((int)lane == leader) base = atomicAdd(outCount, (uint32_t)__popcll(m));
+        if ((int)lane == leader) base = atomicAdd(&outCounts[shard], (uint32_t)__popcll(m));  // survivors stay in their shard
         base = __shfl(base, leader, 64);
         if (alive) {
-            const uint32_t o = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t o = shard * in.cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             qOut.a[o] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x);
             qOut.b[o] = make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix));
             qOut.c[o] = make_float4(contribution.x, contribution.y, contribution.z, light.x);
@@ -359,6 +492,10 @@ bool devAlloc(T** p, size_t n, std::string& err) {
 
 }  // namespace
 
+constexpr uint32_t kMaxSegments = 66;                       // max_bounces <= 64
+constexpr uint32_t kCursorBase = kMaxSegments * kShards;
+constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorStride;
+
 struct FastScene {
     float4* nodes = nullptr;
     float4* tris = nullptr;
@@ -368,7 +505,7 @@ struct FastScene {
     size_t capacity = 0;
     RayQueue q[2] = {};
     HitBuffer hb = {};
-    uint32_t* counts = nullptr;  // [0..15] queue counts, [16..31] trace cursors
+    uint32_t* counts = nullptr;  // per segment b: counts[b*kShards + s]; cursors at kCursorBase + b*kShards + s
     uint2* overflow = nullptr;
     uint32_t overflowCap = 0;
     int traceBlocks = 0;
@@ -397,14 +534,14 @@ bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std:
     int dev = 0, cus = 256;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    fs.traceBlocks = cus * 6;
+    fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : 5);
     uint32_t need = 3 * fs.maxDepth + 4;
     uint32_t cap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;
     if (cap != fs.overflowCap || !fs.overflow) {
         if (!devAlloc(&fs.overflow, (size_t)fs.traceBlocks * kTraceThreads * cap, err)) return false;
         fs.overflowCap = cap;
     }
-    if (!fs.counts && !devAlloc(&fs.counts, 32, err)) return false;
+    if (!fs.counts && !devAlloc(&fs.counts, kCountWords, err)) return false;
     return true;
 }
 
@@ -420,7 +557,9 @@ void fastDestroy(FastScene* fs) {
 
 bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
                 unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, std::string& err) {
-    const size_t items = (size_t)(((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;
+    const uint32_t total = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays incl. tile padding
+    const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
+    const size_t items = (size_t)cap * kShards;
     if (items > fs.capacity) {
         hipStreamSynchronize(stream);
         for (RayQueue& q : fs.q)
@@ -429,42 +568,49 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
         fs.capacity = items;
     }
     const uint32_t lastBounce = s.maxBounces;
-    if (lastBounce + 2 > 16) {
+    if (lastBounce + 2 > kMaxSegments) {
         err = "max_bounces too large for the fast pipeline";
         return false;
     }
-    hipMemsetAsync(fs.counts, 0, 32 * sizeof(uint32_t), stream);
+    hipMemsetAsync(fs.counts, 0, (size_t)kCountWords * sizeof(uint32_t), stream);
     FastView fv{fs.nodes, fs.tris, fs.overflow, fs.overflowCap};
     const dim3 tb(kTraceThreads), tg(fs.traceBlocks);
-    const dim3 sg((unsigned)((items + 255) / 256));
+    const dim3 sg((unsigned)(items / 256));
     const bool cnt = counters != nullptr;
     int ev = 0;
     auto mark = [&]() { if (events) hipEventRecord(events[ev++], stream); };
+    static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
+    static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
+    static const uint32_t envRefill = getenv("OKRT_FAST_REFILL") ? (uint32_t)atoi(getenv("OKRT_FAST_REFILL")) : (uint32_t)kRefillBelow;
+    auto shards = [&](uint32_t b, bool camera) {
+        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, camera ? nullptr : fs.counts + b * kShards,
+                         fs.counts + kCursorBase + b * kShards * kCursorStride};
+    };
     mark();
-    // segment 0
+    // segment 0: camera rays
     if (cnt)
-        hipLaunchKernelGGL((traceKernel<true, true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.counts + 16, counters, rayTotals);
+        hipLaunchKernelGGL((traceKernel<true, true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), counters, rayTotals);
     else
-        hipLaunchKernelGGL((traceKernel<true, false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.counts + 16, counters, rayTotals);
+        hipLaunchKernelGGL((traceKernel<true, false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), counters, rayTotals);
     mark();
     if (cnt)
-        hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.q[1], fs.counts + 1, 0u, lastBounce, accum, result, counters);
+        hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards, 0u, lastBounce, accum, result, counters);
     else
-        hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, fs.counts, fs.q[1], fs.counts + 1, 0u, lastBounce, accum, result, counters);
+        hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards, 0u, lastBounce, accum, result, counters);
     mark();
     // segments 1..lastBounce: queue b lives in q[b & 1]
     for (uint32_t b = 1; b <= lastBounce; ++b) {
         RayQueue& qin = fs.q[b & 1];
         RayQueue& qout = fs.q[(b + 1) & 1];
         if (cnt)
-            hipLaunchKernelGGL((traceKernel<false, true>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, fs.counts + b, fs.counts + 16 + b, counters, rayTotals);
+            hipLaunchKernelGGL((traceKernel<false, true>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), counters, rayTotals);
         else
-            hipLaunchKernelGGL((traceKernel<false, false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, fs.counts + b, fs.counts + 16 + b, counters, rayTotals);
+            hipLaunchKernelGGL((traceKernel<false, false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), counters, rayTotals);
         mark();
         if (cnt)
-            hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, fs.counts + b, qout, fs.counts + b + 1, b, lastBounce, accum, result, counters);
+            hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards, b, lastBounce, accum, result, counters);
         else
-            hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, fs.counts + b, qout, fs.counts + b + 1, b, lastBounce, accum, result, counters);
+            hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards, b, lastBounce, accum, result, counters);
         mark();
     }
     return true;
