@@ -2,8 +2,8 @@
 // the wavefront pipeline that traces it (okrt_fast_build.cpp, okrt_fast_kernel.hip).
 //
 // Layout in HBM (all 16-byte aligned, 128-byte node stride = one L2 line per node visit):
-//   Node4   128 B  four child boxes as SoA rows (minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4]),
-//                  child[4] references, 16 B spare. One visit = 7 x global_load_dwordx4 per lane.
+//   Node4Q   64 B  four child boxes, 8-bit planes on a per-node power-of-two grid, child[4] references.
+//                  One visit = 4 x global_load_dwordx4 per lane.
 //   Tri48    48 B  p2, E1 = p0-p2, E2 = p1-p2 (the reference's Moeller-Trumbore edge convention,
 //                  GPU-Utilities.hlsli:124) + source triangle index (into t0/t1) + instance index.
 //                  One test = 3 x global_load_dwordx4.
@@ -18,13 +18,21 @@
 
 namespace okrt {
 
-struct alignas(16) Node4 {
-    float bmin[3][4];   // [axis][child]
-    float bmax[3][4];
+// Node4Q: four child boxes quantised to 8 bits per plane on a per-node grid (origin + q * 2^e per axis).
+// Boxes are conservative (floor/ceil on a padded grid), so the traversal visits a superset of what exact
+// boxes would: the closest hit is unchanged. 64 B = half an L2 line = 4 x global_load_dwordx4 per visit
+// (the fp32 Node4 of the first version needed 7): the traversal is bound by L1/TA address processing of
+// divergent 16-byte gathers, so loads per visit is the lever.
+struct alignas(16) Node4Q {
+    float origin[3];
+    uint32_t exps;       // IEEE exponent bytes ex | ey << 8 | ez << 16: grid step of axis a = 2^(e_a - 127)
     uint32_t child[4];
-    uint32_t pad[4];
+    uint32_t qlo[3];     // per axis: byte k = child k's lower plane
+    uint32_t pad0;
+    uint32_t qhi[3];     // per axis: byte k = child k's upper plane
+    uint32_t pad1;
 };
-static_assert(sizeof(Node4) == 128, "Node4 is one 128-byte line");
+static_assert(sizeof(Node4Q) == 64, "Node4Q is half a 128-byte line");
 
 struct alignas(16) Tri48 {
     float p2[3];
@@ -49,9 +57,9 @@ struct FastInputs {  // host copies of the uploaded reference tables
 
 // Host-side result of the build (okrt_fast_build.cpp); uploaded by fastBuild.
 struct FastHostScene {
-    std::vector<Node4> nodes;  // nodes[0] is the root (always present, possibly all-empty)
+    std::vector<Node4Q> nodes;  // nodes[0] is the root (always present, possibly all-empty)
     std::vector<Tri48> tris;
-    uint32_t maxDepth = 0;     // deepest leaf, in Node4 levels
+    uint32_t maxDepth = 0;     // deepest leaf, in Node4Q levels
     bool allIdentity = true;   // every instance matrix is the identity (bit-exact with the reference order)
 };
 void buildFastHost(const FastInputs& in, FastHostScene& out);

@@ -163,6 +163,56 @@ bool isIdentity(const float* m) {
     return true;
 }
 
+
+// Quantise up to four child boxes onto a per-node grid. The grid origin is the union's lower corner
+// minus a pad, the step a power of two with 255 steps covering the padded extent; planes are
+// floor/ceil'ed, so every quantised box contains its child (checked in double below). The pad keeps
+// planes that coincide with the node's own faces strictly inside the grid, which absorbs the few-ulp
+// rounding of the kernel's fused slab arithmetic t = fma(q, step/d, (origin - o)/d).
+Node4Q makeNode4Q(const Box* boxes, const uint32_t* refs, int n) {
+    Node4Q nd;
+    std::memset(&nd, 0, sizeof(nd));
+    Box u;
+    for (int i = 0; i < n; ++i) u.grow(boxes[i]);
+    uint32_t exps = 0;
+    double org[3], step[3];
+    for (int a = 0; a < 3; ++a) {
+        double lo = u.mn[a], hi = u.mx[a];
+        double pad = std::max({(hi - lo) * (1.0 / 512.0), std::max(std::fabs(lo), std::fabs(hi)) * 4e-6, 1e-30});
+        float o = (float)(lo - pad);
+        if ((double)o > lo - pad) o = std::nextafterf(o, -INFINITY);
+        double ext = (hi + pad) - (double)o;
+        int k;
+        std::frexp(ext / 255.0, &k);  // ext/255 = m * 2^k, m in [0.5, 1)  ->  2^k >= ext/255
+        k = std::min(std::max(k, -126), 127);
+        while ((double)o + 255.0 * std::ldexp(1.0, k) < hi && k < 127) ++k;
+        nd.origin[a] = o;
+        org[a] = o;
+        step[a] = std::ldexp(1.0, k);
+        exps |= (uint32_t)(k + 127) << (8 * a);
+    }
+    nd.exps = exps;
+    for (int i = 0; i < 4; ++i) {
+        if (i >= n) {
+            nd.child[i] = kEmptyRef;
+            for (int a = 0; a < 3; ++a) {  // inverted: can never be entered
+                nd.qlo[a] |= 255u << (8 * i);
+            }
+            continue;
+        }
+        nd.child[i] = refs[i];
+        for (int a = 0; a < 3; ++a) {
+            double ql = std::floor((boxes[i].mn[a] - org[a]) / step[a]);
+            double qh = std::ceil((boxes[i].mx[a] - org[a]) / step[a]);
+            ql = std::min(std::max(ql, 0.0), 255.0);
+            qh = std::min(std::max(qh, 0.0), 255.0);
+            nd.qlo[a] |= (uint32_t)ql << (8 * i);
+            nd.qhi[a] |= (uint32_t)qh << (8 * i);
+        }
+    }
+    return nd;
+}
+
 struct Emitter {
     const Builder& b;
     FastHostScene& out;
@@ -205,29 +255,22 @@ struct Emitter {
             kids[pick] = c.left;
             kids[n++] = c.right;
         }
-        Node4 nd;
-        std::memset(&nd, 0, sizeof(nd));
+        Box boxes[4];
+        uint32_t refs[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
         uint32_t childSlot[4];
-        for (int i = 0; i < 4; ++i) {
-            if (i >= n) {
-                for (int k = 0; k < 3; ++k) nd.bmin[k][i] = nd.bmax[k][i] = NAN;  // every slab comparison fails
-                nd.child[i] = kEmptyRef;
-                continue;
-            }
+        for (int i = 0; i < n; ++i) {
             const Node2& c = b.nodes[kids[i]];
-            for (int k = 0; k < 3; ++k) {
-                nd.bmin[k][i] = c.box.mn[k];
-                nd.bmax[k][i] = c.box.mx[k];
-            }
+            boxes[i] = c.box;
             if (c.left < 0) {
-                nd.child[i] = emitLeaf(c);
+                refs[i] = emitLeaf(c);
                 maxDepth = std::max(maxDepth, depth + 1);
             } else {
                 childSlot[i] = (uint32_t)out.nodes.size();
                 out.nodes.emplace_back();
-                nd.child[i] = childSlot[i];
+                refs[i] = childSlot[i];
             }
         }
+        Node4Q nd = makeNode4Q(boxes, refs, n);
         out.nodes[slot] = nd;
         for (int i = 0; i < n; ++i)
             if (b.nodes[kids[i]].left >= 0) emitNode(childSlot[i], kids[i], depth + 1);
@@ -300,12 +343,7 @@ void buildFastHost(const FastInputs& in, FastHostScene& out) {
     }
 
     out.nodes.emplace_back();
-    Node4& root = out.nodes[0];
-    std::memset(&root, 0, sizeof(root));
-    for (int i = 0; i < 4; ++i) {
-        for (int k = 0; k < 3; ++k) root.bmin[k][i] = root.bmax[k][i] = NAN;
-        root.child[i] = kEmptyRef;
-    }
+    out.nodes[0] = makeNode4Q(nullptr, nullptr, 0);  // all-empty root
     if (prims.empty()) return;
 
     // 3. BVH2
@@ -317,11 +355,8 @@ void buildFastHost(const FastInputs& in, FastHostScene& out) {
     Emitter e{b, out};
     out.tris.reserve(prims.size());
     if (b.nodes[r].left < 0) {  // a single leaf: hang it under the root
-        for (int k = 0; k < 3; ++k) {
-            root.bmin[k][0] = b.nodes[r].box.mn[k];
-            root.bmax[k][0] = b.nodes[r].box.mx[k];
-        }
-        out.nodes[0].child[0] = e.emitLeaf(b.nodes[r]);
+        uint32_t ref = e.emitLeaf(b.nodes[r]);
+        out.nodes[0] = makeNode4Q(&b.nodes[r].box, &ref, 1);
         out.maxDepth = 1;
         return;
     }
@@ -393,13 +428,20 @@ extern "C" int okrt_debug_fast_closest_hit(const void* triPos, uint32_t numTris,
                 }
                 continue;
             }
-            const Node4& n = fs.nodes[cur];
+            const Node4Q& n = fs.nodes[cur];
             for (int k = 0; k < 4; ++k) {
+                if (n.child[k] == kEmptyRef) continue;
                 float tn = -FLT_MAX, tf = FLT_MAX;
-                for (int a = 0; a < 3; ++a) {
-                    float t0 = (n.bmin[a][k] - o[a]) * inv[a], t1 = (n.bmax[a][k] - o[a]) * inv[a];
-                    tn = std::fmax(tn, std::fmin(t0, t1));
-                    tf = std::fmin(tf, std::fmax(t0, t1));
+                for (int a = 0; a < 3; ++a) {  // the kernel's fused slab arithmetic
+                    uint32_t eb = (n.exps >> (8 * a)) & 255u, bits = eb << 23;
+                    float sc;
+                    std::memcpy(&sc, &bits, 4);
+                    float iq = std::fmin(std::fmax(inv[a], -1e30f), 1e30f);
+                    float A = sc * iq, B = (n.origin[a] - o[a]) * iq;
+                    float ql = (float)((n.qlo[a] >> (8 * k)) & 255u), qh = (float)((n.qhi[a] >> (8 * k)) & 255u);
+                    float tnear = std::fmaf(iq >= 0.f ? ql : qh, A, B), tfar = std::fmaf(iq >= 0.f ? qh : ql, A, B);
+                    tn = std::fmax(tn, tnear);
+                    tf = std::fmin(tf, tfar);
                 }
                 if (tf >= tn && tf > 0.f && tn < best) stack.push_back(n.child[k]);
             }

@@ -21,10 +21,10 @@
 //   * per-lane traversal stack in LDS ([entry][thread], conflict-free), entries carry the child's
 //     entry distance so stale entries are dropped without touching memory; deeper levels spill to
 //     a per-thread HBM slab (sized from the tree depth at build time);
-//   * one Node4 visit = 7 x 16-byte loads of one 128-byte line; children are visited nearest
-//     first (4-key sorting network), a Tri48 test = 3 x 16-byte loads;
-//   * same arithmetic as the reference for what decides the result: slab test (b-o)*(1/d) with
-//     the ray re-normalised as the shader does for each instance, Moeller-Trumbore with the
+//   * one Node4Q visit = 4 x 16-byte loads (64 B, 8-bit child planes on a per-node grid, conservative);
+//     children are visited nearest first (4-key sorting network), a Tri48 test = 3 x 16-byte loads;
+//   * same arithmetic as the reference for what decides the result: the ray re-normalised as the
+//     shader does for each instance, Moeller-Trumbore with the
 //     shader's edge convention, hit distance = length(dir*t) (RaytracerCS.hlsl:276,285,306-316),
 //     so for identity instances (all benchmark scenes) the closest hit equals the reference's bit
 //     for bit; only equal-distance ties may resolve to a different triangle.
@@ -49,10 +49,10 @@ constexpr uint32_t kCursorStride = 32;  // words: one cursor per 128-byte line (
 struct ShardView {
     uint32_t cap, total;
     uint32_t batch, xcdAffinity, refillBelow;  // tunables (developer knobs: OKRT_FAST_BATCH / _AFFINITY / _REFILL)
-    const uint32_t* counts;  // nullptr for camera rays
+    const uint32_t* counts;  // counts[s * kCursorStride]; nullptr for camera rays
     uint32_t* cursors;       // cursors[s * kCursorStride]
     __device__ uint32_t count(uint32_t s) const {
-        if (counts) return counts[s];
+        if (counts) return counts[s * kCursorStride];
         const uint32_t lo = s * cap;
         return total > lo ? min(total - lo, cap) : 0u;
     }
@@ -70,7 +70,7 @@ struct HitBuffer {
 };
 
 struct FastView {
-    const float4* nodes;   // Node4 as 8 x float4
+    const uint4* nodes;    // Node4Q as 4 x uint4
     const float4* tris;    // Tri48 as 3 x float4
     uint2* overflow;       // per-thread spill slab
     uint32_t overflowCap;  // entries per thread
@@ -89,8 +89,8 @@ template <bool PRIMARY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
                                                             HitBuffer hb, ShardView sv, unsigned long long* counters,
                                                             unsigned long long* rayTotals) {
-    __shared__ uint32_t sRef[kLdsStack][kTraceThreads];
-    __shared__ float sDist[kLdsStack][kTraceThreads];
+    // (ref, entry distance) pairs, [entry][thread]; row kLdsStack is a dummy target for predicated-off pushes
+    __shared__ uint2 sStack[kLdsStack + 1][kTraceThreads];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     uint2* myOverflow = fv.overflow + (size_t)(blockIdx.x * kTraceThreads + tid) * fv.overflowCap;
     if (!COUNT && blockIdx.x == 0 && tid == 0) {  // rays of this launch, always counted (okrt_counters.pixels / .segments)
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
     uint32_t rayIdx = kInvalid;   // the ray this lane is tracing
     uint32_t cur = kDone;         // node/leaf reference being processed, kDone = lane idle
     uint32_t sp = 0;
-    V3 ro = mk(0, 0, 0), rdir = mk(0, 0, 0), inv = mk(0, 0, 0);
+    V3 ro = mk(0, 0, 0), rdir = mk(0, 0, 0), iq = mk(0, 0, 0);
     float best = kFltMax, hbu = 0.f, hbv = 0.f;
     uint32_t hitIdx = kInvalid, hitTri = kInvalid;
     uint32_t nNodes = 0, nTris = 0, nSeg = 0;
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                                 nSeg++;
                                 ro = ray.origin;
                                 rdir = normalize(ray.direction);
-                                inv = rcp3(rdir);
+                                iq = rcp3(rdir);  // clamped to +-1e30 so that 0 * inf cannot poison the fused slab arithmetic
+                        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
                                 best = kFltMax;
                                 hitIdx = kInvalid;
                                 hitTri = kInvalid;
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                         ro = ray.origin;
                         // the shader re-normalises the direction per instance (RaytracerCS.hlsl:276)
                         rdir = normalize(ray.direction);
-                        inv = rcp3(rdir);
+                        iq = rcp3(rdir);  // clamped to +-1e30 so that 0 * inf cannot poison the fused slab arithmetic
+                        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
                         best = kFltMax;
                         hitIdx = kInvalid;
                         hitTri = kInvalid;
@@ -266,65 +268,68 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
         {
         OKRT_T0
         while (cur != kDone && !(cur & kLeafBit)) {
-            const float4* np = fv.nodes + (size_t)cur * 8;
-            const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
-            const float4 chf = np[6];
+            const uint4* np = fv.nodes + (size_t)cur * 4;
+            const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             if (COUNT) nNodes++;
             float tn[4];
-            uint32_t ch[4] = {__float_as_uint(chf.x), __float_as_uint(chf.y), __float_as_uint(chf.z), __float_as_uint(chf.w)};
-            const float bminx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bminy[4] = {mny.x, mny.y, mny.z, mny.w}, bminz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
-            const float bmaxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, bmaxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bmaxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+            uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
+            // slab test on the node's grid: t = (origin + q*step - o)/d = fma(q, step/d, (origin - o)/d)
+            const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
+            const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
+            const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
+            // entry planes are the lower ones for a positive direction component, the upper ones otherwise
+            const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
+            const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
+            const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {  // GPU-Utilities.hlsli:183-197
-                float ax = (bminx[k] - ro.x) * inv.x, bx = (bmaxx[k] - ro.x) * inv.x;
-                float ay = (bminy[k] - ro.y) * inv.y, by = (bmaxy[k] - ro.y) * inv.y;
-                float az = (bminz[k] - ro.z) * inv.z, bz = (bmaxz[k] - ro.z) * inv.z;
-                float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-                float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+            for (int k = 0; k < 4; ++k) {
+                const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
+                                          fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
+                const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
+                                         fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
                 bool hit = tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef;
                 tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
             }
-            // sort the four (distance, child) pairs ascending: 5-comparator network
-#define OKRT_CSWAP(i, j)                                   \
-    if (tn[j] < tn[i]) {                                   \
-        float tf_ = tn[i]; tn[i] = tn[j]; tn[j] = tf_;     \
-        uint32_t tc_ = ch[i]; ch[i] = ch[j]; ch[j] = tc_;  \
+            // sort the four (distance, child) pairs ascending: 5-comparator network, select-based (no branches)
+#define OKRT_CSWAP(i, j)                                              \
+    {                                                                 \
+        const bool sw_ = tn[j] < tn[i];                               \
+        const float lo_ = sw_ ? tn[j] : tn[i], hi_ = sw_ ? tn[i] : tn[j];     \
+        const uint32_t cl_ = sw_ ? ch[j] : ch[i], chh_ = sw_ ? ch[i] : ch[j]; \
+        tn[i] = lo_; tn[j] = hi_; ch[i] = cl_; ch[j] = chh_;          \
     }
             OKRT_CSWAP(0, 1) OKRT_CSWAP(2, 3) OKRT_CSWAP(0, 2) OKRT_CSWAP(1, 3) OKRT_CSWAP(1, 2)
 #undef OKRT_CSWAP
-            // push the far ones (3,2,1), continue with the nearest
+            // hits are now ch[0..n-1]; push n-1 far ones so that ch[1] ends on top, continue with ch[0]
+            const uint32_t n = (tn[0] < kFltMax) + (tn[1] < kFltMax) + (tn[2] < kFltMax) + (tn[3] < kFltMax);
+            if (sp + 3 <= (uint32_t)kLdsStack) {  // fast path: three unconditional 8-byte LDS writes, misses go to the dummy row
+                const uint32_t top = sp + n;      // entry k (1..n-1) lands at sp + n-1-k
+                sStack[1 < n ? top - 2 : kLdsStack][tid] = make_uint2(ch[1], __float_as_uint(tn[1]));
+                sStack[2 < n ? top - 3 : kLdsStack][tid] = make_uint2(ch[2], __float_as_uint(tn[2]));
+                sStack[3 < n ? top - 4 : kLdsStack][tid] = make_uint2(ch[3], __float_as_uint(tn[3]));
+                sp += n > 1 ? n - 1 : 0;
+            } else {  // deep in the tree: spill to the per-thread HBM slab
 #pragma unroll
-            for (int k = 3; k >= 1; --k) {
-                if (tn[k] < kFltMax) {
-                    if (sp < (uint32_t)kLdsStack) {
-                        sRef[sp][tid] = ch[k];
-                        sDist[sp][tid] = tn[k];
-                    } else if (sp - kLdsStack < fv.overflowCap) {
-                        myOverflow[sp - kLdsStack] = make_uint2(ch[k], __float_as_uint(tn[k]));
-                    } else {
-                        continue;  // cannot happen: the slab is sized from the tree depth
+                for (int k = 3; k >= 1; --k) {
+                    if (tn[k] < kFltMax) {
+                        if (sp < (uint32_t)kLdsStack) {
+                            sStack[sp][tid] = make_uint2(ch[k], __float_as_uint(tn[k]));
+                        } else if (sp - kLdsStack < fv.overflowCap) {
+                            myOverflow[sp - kLdsStack] = make_uint2(ch[k], __float_as_uint(tn[k]));
+                        } else {
+                            continue;  // cannot happen: the slab is sized from the tree depth
+                        }
+                        sp++;
                     }
-                    sp++;
                 }
             }
-            if (tn[0] < kFltMax) {
-                cur = ch[0];
-            } else {
-                cur = kDone;
+            cur = n ? ch[0] : kDone;
+            if (!n) {
                 while (sp > 0) {  // pop, dropping entries the current best already beats
                     --sp;
-                    uint32_t r;
-                    float d;
-                    if (sp < (uint32_t)kLdsStack) {
-                        r = sRef[sp][tid];
-                        d = sDist[sp][tid];
-                    } else {
-                        uint2 e = myOverflow[sp - kLdsStack];
-                        r = e.x;
-                        d = __uint_as_float(e.y);
-                    }
-                    if (d < best) {
-                        cur = r;
+                    const uint2 e = sp < (uint32_t)kLdsStack ? sStack[sp][tid] : myOverflow[sp - kLdsStack];
+                    if (__uint_as_float(e.y) < best) {
+                        cur = e.x;
                         break;
                     }
                 }
@@ -358,18 +363,9 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
             cur = kDone;
             while (sp > 0) {
                 --sp;
-                uint32_t r;
-                float d;
-                if (sp < (uint32_t)kLdsStack) {
-                    r = sRef[sp][tid];
-                    d = sDist[sp][tid];
-                } else {
-                    uint2 e = myOverflow[sp - kLdsStack];
-                    r = e.x;
-                    d = __uint_as_float(e.y);
-                }
-                if (d < best) {
-                    cur = r;
+                const uint2 e = sp < (uint32_t)kLdsStack ? sStack[sp][tid] : myOverflow[sp - kLdsStack];
+                if (__uint_as_float(e.y) < best) {
+                    cur = e.x;
                     break;
                 }
             }
@@ -450,20 +446,26 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
         }
         if (!alive) writePixel(rd, light, 0, 0, accum, result, pix);
     }
-    // ballot compaction of the surviving paths into the next queue
+    // ballot compaction of the surviving paths into the next queue: ranks inside the wave by ballot, waves inside
+    // the block through LDS, ONE atomic per block on the shard's counter (one per wave saturated the counter line)
+    __shared__ uint32_t sWaveCount[4], sBlockBase;
     const unsigned long long m = __ballot(alive);
-    if (m) {
-        uint32_t base = 0;
-        const int leader = __ffsll((long long)m) - 1;
-        if ((int)lane == leader) base = atomicAdd(&outCounts[shard], (uint32_t)__popcll(m));  // survivors stay in their shard
-        base = __shfl(base, leader, 64);
-        if (alive) {
-            const uint32_t o = shard * in.cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            qOut.a[o] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x);
-            qOut.b[o] = make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix));
-            qOut.c[o] = make_float4(contribution.x, contribution.y, contribution.z, light.x);
-            qOut.d[o] = make_float2(light.y, light.z);
-        }
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane == 0) sWaveCount[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = sWaveCount[0] + sWaveCount[1] + sWaveCount[2] + sWaveCount[3];
+        sBlockBase = tot ? atomicAdd(&outCounts[shard * kCursorStride], tot) : 0u;  // survivors stay in their shard
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += sWaveCount[w];
+        const uint32_t o = shard * in.cap + sBlockBase + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        qOut.a[o] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x);
+        qOut.b[o] = make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix));
+        qOut.c[o] = make_float4(contribution.x, contribution.y, contribution.z, light.x);
+        qOut.d[o] = make_float2(light.y, light.z);
     }
     if (COUNT && counters) {
         uint32_t vals[5] = {(FIRST && valid) ? 1u : 0u, cnt.meshHits, cnt.sphereHits, cnt.texTaps, cnt.envTaps};
@@ -493,11 +495,11 @@ bool devAlloc(T** p, size_t n, std::string& err) {
 }  // namespace
 
 constexpr uint32_t kMaxSegments = 66;                       // max_bounces <= 64
-constexpr uint32_t kCursorBase = kMaxSegments * kShards;
+constexpr uint32_t kCursorBase = kMaxSegments * kShards * kCursorStride;
 constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorStride;
 
 struct FastScene {
-    float4* nodes = nullptr;
+    uint4* nodes = nullptr;
     float4* tris = nullptr;
     uint32_t numNodes = 0, numTris = 0, maxDepth = 0;
     bool allIdentity = true;
@@ -505,7 +507,8 @@ struct FastScene {
     size_t capacity = 0;
     RayQueue q[2] = {};
     HitBuffer hb = {};
-    uint32_t* counts = nullptr;  // per segment b: counts[b*kShards + s]; cursors at kCursorBase + b*kShards + s
+    uint32_t* counts = nullptr;  // per segment b, shard s: count at (b*kShards + s)*kCursorStride, cursor at kCursorBase + the same
+                                 // (every counter on its own 128-byte line: device-scope atomics serialise per line)
     uint2* overflow = nullptr;
     uint32_t overflowCap = 0;
     int traceBlocks = 0;
@@ -520,9 +523,9 @@ bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std:
     fs.numTris = (uint32_t)host.tris.size();
     fs.maxDepth = host.maxDepth;
     fs.allIdentity = host.allIdentity;
-    if (!devAlloc(&fs.nodes, host.nodes.size() * 8, err)) return false;
+    if (!devAlloc(&fs.nodes, host.nodes.size() * 4, err)) return false;
     if (!devAlloc(&fs.tris, std::max<size_t>(host.tris.size(), 1) * 3, err)) return false;
-    hipError_t e = hipMemcpyAsync(fs.nodes, host.nodes.data(), host.nodes.size() * sizeof(Node4), hipMemcpyHostToDevice, stream);
+    hipError_t e = hipMemcpyAsync(fs.nodes, host.nodes.data(), host.nodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess && !host.tris.empty())
         e = hipMemcpyAsync(fs.tris, host.tris.data(), host.tris.size() * sizeof(Tri48), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `host` dies at return
@@ -583,7 +586,7 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
     static const uint32_t envRefill = getenv("OKRT_FAST_REFILL") ? (uint32_t)atoi(getenv("OKRT_FAST_REFILL")) : (uint32_t)kRefillBelow;
     auto shards = [&](uint32_t b, bool camera) {
-        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, camera ? nullptr : fs.counts + b * kShards,
+        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
                          fs.counts + kCursorBase + b * kShards * kCursorStride};
     };
     mark();
@@ -594,9 +597,9 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
         hipLaunchKernelGGL((traceKernel<true, false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), counters, rayTotals);
     mark();
     if (cnt)
-        hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards, 0u, lastBounce, accum, result, counters);
+        hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, counters);
     else
-        hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards, 0u, lastBounce, accum, result, counters);
+        hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, counters);
     mark();
     // segments 1..lastBounce: queue b lives in q[b & 1]
     for (uint32_t b = 1; b <= lastBounce; ++b) {
@@ -608,9 +611,9 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
             hipLaunchKernelGGL((traceKernel<false, false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), counters, rayTotals);
         mark();
         if (cnt)
-            hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards, b, lastBounce, accum, result, counters);
+            hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, counters);
         else
-            hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards, b, lastBounce, accum, result, counters);
+            hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, counters);
         mark();
     }
     return true;
