@@ -2,13 +2,12 @@
 //
 // One frame = a short pipeline of kernels over ray queues in HBM (per path segment):
 //
-//   traceKernel<PRIMARY>   persistent waves; camera rays are generated in-register from the pixel
-//                          index (no ray buffer), closest hit through the Node4/Tri48 structure,
-//                          hit record (20 B) written per ray
-//   shadeKernel<FIRST>     regenerates the camera ray (same RNG stream), material/texture fetch,
-//                          lights, BSDF sample; finished paths accumulate into the framebuffer,
-//                          survivors are ballot-compacted into the next ray queue (56 B per ray)
-//   traceKernel<QUEUED> / shadeKernel<NEXT>   ... one pair per further segment
+//   generateKernel         camera rays for the owned pixels, in 8x8-tile order, into ray queue 0 (32 B per ray)
+//   traceKernel            persistent waves: closest hit through the Node4Q/Tri48 structure for every ray of
+//                          the queue, hit record (20 B) written per ray
+//   shadeKernel            material/texture fetch, lights, BSDF sample; finished paths accumulate into the
+//                          framebuffer, survivors are compacted into the next ray queue (56 B per ray)
+//   traceKernel / shadeKernel   ... one pair per further segment
 //
 // Traversal (what the profile is dominated by) is built for CDNA4:
 //   * wave64, 256-thread blocks, persistent: each wave REFILLS its idle lanes when fewer than
@@ -85,19 +84,35 @@ OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t
     return px < t.W && lrow < t.rows;
 }
 
-template <bool PRIMARY, bool COUNT>
+// Camera rays for every owned pixel, in tile order (position i <-> pixel by primaryPixel): origin, direction,
+// RNG state after the 4 camera draws, framebuffer offset. Padding positions (outside the image) get pix = kInvalid.
+__global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileView tile, RayQueue q, uint32_t total) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    uint32_t px, lrow, seed = 0, pix = kInvalid;
+    Ray ray;
+    ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
+    if (primaryPixel(tile, i, px, lrow)) {
+        ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
+        pix = lrow * tile.W + px;
+    }
+    q.a[i] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x);
+    q.b[i] = make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix));
+}
+
+template <bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
-                                                            HitBuffer hb, ShardView sv, unsigned long long* counters,
-                                                            unsigned long long* rayTotals) {
+                                                            HitBuffer hb, ShardView sv, uint32_t isCamera,
+                                                            unsigned long long* counters, unsigned long long* rayTotals) {
     // (ref, entry distance) pairs, [entry][thread]; row kLdsStack is a dummy target for predicated-off pushes
     __shared__ uint2 sStack[kLdsStack + 1][kTraceThreads];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     uint2* myOverflow = fv.overflow + (size_t)(blockIdx.x * kTraceThreads + tid) * fv.overflowCap;
     if (!COUNT && blockIdx.x == 0 && tid == 0) {  // rays of this launch, always counted (okrt_counters.pixels / .segments)
         unsigned long long n = 0;
-        if (PRIMARY) n = (unsigned long long)tile.W * tile.rows;
+        if (isCamera) n = (unsigned long long)tile.W * tile.rows;
         else for (uint32_t k = 0; k < kShards; ++k) n += sv.count(k);
-        if (PRIMARY) atomicAdd(&rayTotals[0], n);
+        if (isCamera) atomicAdd(&rayTotals[0], n);
         atomicAdd(&rayTotals[1], n);
     }
     // wave-uniform work-fetch state
@@ -108,7 +123,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
     bool havePre = false;
 
     uint32_t rayIdx = kInvalid;   // the ray this lane is tracing
-    uint32_t cur = kDone;         // node/leaf reference being processed, kDone = lane idle
+    uint32_t cur = kDone;         // node/leaf reference being processed, kDone = nothing
+    uint32_t post = kDone;        // a leaf found earlier and postponed (speculative traversal), kDone = none
     uint32_t sp = 0;
     V3 ro = mk(0, 0, 0), rdir = mk(0, 0, 0), iq = mk(0, 0, 0);
     float best = kFltMax, hbu = 0.f, hbv = 0.f;
@@ -124,6 +140,43 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
 #define OKRT_T0
 #define OKRT_T1(acc)
 #endif
+    // pop the next entry the current best does not already beat
+    auto popNext = [&]() -> uint32_t {
+        while (sp > 0) {
+            --sp;
+            const uint2 e = sp < (uint32_t)kLdsStack ? sStack[sp][tid] : myOverflow[sp - kLdsStack];
+            if (__uint_as_float(e.y) < best) return e.x;
+        }
+        return kDone;
+    };
+    // Moeller-Trumbore on a leaf's triangles; the next triangle's 48 bytes are requested before the current one is tested
+    auto intersectLeaf = [&](uint32_t leaf) {
+        const uint32_t count = ((leaf >> 27) & 15u) + 1u;
+        const float4* tp = fv.tris + (size_t)(leaf & 0x07FFFFFFu) * 3;
+        float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        for (uint32_t j = 0; j < count; ++j) {
+            float4 u0 = t0, u1 = t1, u2 = t2;
+            if (j + 1 < count) {
+                tp += 3;
+                u0 = tp[0]; u1 = tp[1]; u2 = tp[2];
+            }
+            if (COUNT) nTris++;
+            float bu = 0.f, bv = 0.f;
+            const float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
+            if (t > 0.f) {
+                const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314 with M = identity (world-space triangles)
+                if (d < best) {
+                    best = d;
+                    hbu = bu;
+                    hbv = bv;
+                    hitTri = __float_as_uint(t0.w);
+                    hitIdx = __float_as_uint(t1.w);
+                }
+            }
+            t0 = u0; t1 = u1; t2 = u2;
+        }
+    };
+
     for (;;) {
 #ifdef OKRT_STAMPS
         nIter++;
@@ -141,40 +194,6 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                 hb.tri[rayIdx] = hitTri;
                 rayIdx = kInvalid;
             }
-            if (PRIMARY && sv.xcdAffinity == 2) {  // A/B: the first version's fetch (one shared cursor, one atomic per refill)
-                if (!exhausted) {
-                    bool sawEnd = false;
-                    if (cur == kDone) {
-                        const unsigned long long idle2 = __ballot(cur == kDone);
-                        const uint32_t want = (uint32_t)__popcll(idle2);
-                        uint32_t base = 0;
-                        const int leader = __ffsll((long long)idle2) - 1;
-                        if ((int)lane == leader) base = atomicAdd(&sv.cursors[0], want);
-                        base = __shfl(base, leader, 64);
-                        const uint32_t mine = base + (uint32_t)__popcll(idle2 & ((1ull << lane) - 1ull));
-                        sawEnd = mine >= sv.total;
-                        if (!sawEnd) {
-                            uint32_t px, lrow, seed;
-                            if (primaryPixel(tile, mine, px, lrow)) {
-                                Ray ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
-                                rayIdx = mine;
-                                nSeg++;
-                                ro = ray.origin;
-                                rdir = normalize(ray.direction);
-                                iq = rcp3(rdir);  // clamped to +-1e30 so that 0 * inf cannot poison the fused slab arithmetic
-                        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
-                                best = kFltMax;
-                                hitIdx = kInvalid;
-                                hitTri = kInvalid;
-                                hbu = hbv = 0.f;
-                                sp = 0;
-                                cur = 0;
-                            }
-                        }
-                    }
-                    exhausted = __ballot(sawEnd) != 0ull;
-                }
-            } else
             for (int round = 0; round < 2 && !exhausted; ++round) {
                 const unsigned long long need = __ballot(cur == kDone);
                 if (!need) break;
@@ -224,18 +243,11 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                 const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (cur == kDone && rank < avail) {
                     const uint32_t mine = resNext + rank;
-                    bool valid = true;
+                    const float4 A = q.a[mine], B = q.b[mine];
                     Ray ray;
-                    if (PRIMARY) {
-                        uint32_t px, lrow, seed;
-                        valid = primaryPixel(tile, mine, px, lrow);
-                        if (valid) ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
-                    } else {
-                        float4 A = q.a[mine], B = q.b[mine];
-                        ray.origin = mk(A.x, A.y, A.z);
-                        ray.direction = mk(A.w, B.x, B.y);
-                    }
-                    if (valid) {
+                    ray.origin = mk(A.x, A.y, A.z);
+                    ray.direction = mk(A.w, B.x, B.y);
+                    if (__float_as_uint(B.w) != kInvalid) {  // camera-ray padding outside the image carries pix = kInvalid
                         rayIdx = mine;
                         nSeg++;
                         ro = ray.origin;
@@ -323,16 +335,12 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                     }
                 }
             }
-            cur = n ? ch[0] : kDone;
-            if (!n) {
-                while (sp > 0) {  // pop, dropping entries the current best already beats
-                    --sp;
-                    const uint2 e = sp < (uint32_t)kLdsStack ? sStack[sp][tid] : myOverflow[sp - kLdsStack];
-                    if (__uint_as_float(e.y) < best) {
-                        cur = e.x;
-                        break;
-                    }
-                }
+            cur = n ? ch[0] : popNext();
+            // speculative traversal: a lane that reaches a leaf parks it and keeps descending, so that it does not
+            // idle while the rest of the wave is still in this loop; both leaves are intersected below
+            if (cur != kDone && (cur & kLeafBit) && post == kDone) {
+                post = cur;
+                cur = popNext();
             }
         }
 
@@ -341,34 +349,13 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
 
         // ---- leaf: Moeller-Trumbore on its triangles -------------------------------------------------
         OKRT_T0
-        if (cur != kDone) {
-            const uint32_t first = cur & 0x07FFFFFFu, count = ((cur >> 27) & 15u) + 1u;
-            for (uint32_t j = 0; j < count; ++j) {
-                const float4* tp = fv.tris + (size_t)(first + j) * 3;
-                const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                if (COUNT) nTris++;
-                float bu = 0.f, bv = 0.f;
-                float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
-                if (t > 0.f) {
-                    float d = length(rdir * t);  // RaytracerCS.hlsl:311-314 with M = identity (world-space triangles)
-                    if (d < best) {
-                        best = d;
-                        hbu = bu;
-                        hbv = bv;
-                        hitTri = __float_as_uint(t0.w);
-                        hitIdx = __float_as_uint(t1.w);
-                    }
-                }
-            }
-            cur = kDone;
-            while (sp > 0) {
-                --sp;
-                const uint2 e = sp < (uint32_t)kLdsStack ? sStack[sp][tid] : myOverflow[sp - kLdsStack];
-                if (__uint_as_float(e.y) < best) {
-                    cur = e.x;
-                    break;
-                }
-            }
+        if (post != kDone) {
+            intersectLeaf(post);
+            post = kDone;
+        }
+        if (cur != kDone && (cur & kLeafBit)) {
+            intersectLeaf(cur);
+            cur = popNext();
         }
         OKRT_T1(tLeaf)
     }
@@ -409,20 +396,15 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
     uint32_t seed = 0, pix = 0;
     bool valid = i < total;
     if (valid) {
-        if (FIRST) {
-            uint32_t px, lrow;
-            valid = primaryPixel(tile, i, px, lrow);
-            if (valid) {
-                ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
-                pix = lrow * tile.W + px;
-            }
-        } else {
-            float4 A = qIn.a[i], B = qIn.b[i], C = qIn.c[i];
-            float2 D = qIn.d[i];
-            ray.origin = mk(A.x, A.y, A.z);
-            ray.direction = mk(A.w, B.x, B.y);
-            seed = __float_as_uint(B.z);
-            pix = __float_as_uint(B.w);
+        const float4 A = qIn.a[i], B = qIn.b[i];
+        ray.origin = mk(A.x, A.y, A.z);
+        ray.direction = mk(A.w, B.x, B.y);
+        seed = __float_as_uint(B.z);
+        pix = __float_as_uint(B.w);
+        valid = pix != kInvalid;
+        if (!FIRST) {  // camera rays start with throughput 1 and no radiance; later segments carry them
+            const float4 C = qIn.c[i];
+            const float2 D = qIn.d[i];
             contribution = mk(C.x, C.y, C.z);
             light = mk(C.w, D.x, D.y);
         }
@@ -537,7 +519,7 @@ bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std:
     int dev = 0, cus = 256;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : 5);
+    fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : 6);
     uint32_t need = 3 * fs.maxDepth + 4;
     uint32_t cap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;
     if (cap != fs.overflowCap || !fs.overflow) {
@@ -590,11 +572,12 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
                          fs.counts + kCursorBase + b * kShards * kCursorStride};
     };
     mark();
-    // segment 0: camera rays
+    // segment 0: camera rays into q[0] (a, b only), then the same trace kernel as every other segment
+    hipLaunchKernelGGL(generateKernel, sg, dim3(256), 0, stream, rd, t, fs.q[0], total);
     if (cnt)
-        hipLaunchKernelGGL((traceKernel<true, true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), counters, rayTotals);
+        hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), 1u, counters, rayTotals);
     else
-        hipLaunchKernelGGL((traceKernel<true, false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), counters, rayTotals);
+        hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), 1u, counters, rayTotals);
     mark();
     if (cnt)
         hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, counters);
@@ -606,9 +589,9 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
         RayQueue& qin = fs.q[b & 1];
         RayQueue& qout = fs.q[(b + 1) & 1];
         if (cnt)
-            hipLaunchKernelGGL((traceKernel<false, true>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), counters, rayTotals);
+            hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals);
         else
-            hipLaunchKernelGGL((traceKernel<false, false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), counters, rayTotals);
+            hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals);
         mark();
         if (cnt)
             hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, counters);
