@@ -113,6 +113,11 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
         args.gpus = world
 
+    if world > 1:
+        # torch bundles its own HIP runtime (same soname as /opt/rocm's). It must be loaded BEFORE libokrt.so so that
+        # both share ONE runtime instance (device pointers and streams cross the boundary); two runtimes in a process
+        # cannot both open the GPU.
+        import torch  # noqa: F401
     abi = importlib.import_module("gpu-raytracer_amd._abi")
     scenes = importlib.import_module("gpu-raytracer_amd.scenes")
     fns = abi.load_device_library()  # raises if libokrt.so is missing: no fallback
@@ -121,13 +126,24 @@ def main():
     desc = getattr(scenes, builder)(**kwargs)
 
     dist = torch = None
+    backend, device_index = "none", local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if ndev >= world:
+            backend = "nccl"  # RCCL: one GPU per rank, tiles move GPU -> GPU over xGMI
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # rehearsal only (fewer GPUs than ranks, e.g. 2 ranks on a 1-GPU box): ranks share a GPU and the tiles
+            # are gathered through host memory with gloo; everything but the RCCL transport is exercised
+            backend = "gloo"
+            device_index = local_rank % max(ndev, 1)
+            torch.cuda.set_device(device_index)
+            dist.init_process_group("gloo")
 
-    rt, scene, res = scenes.instantiate(desc, W, H, device=local_rank)
+    rt, scene, res = scenes.instantiate(desc, W, H, device=device_index)
     ctx = rt.ctx
     ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
 
@@ -140,16 +156,20 @@ def main():
             n = sum(min(STRIPE_ROWS, H - s * STRIPE_ROWS) for s in range(r, (H + STRIPE_ROWS - 1) // STRIPE_ROWS, world))
             max_rows = max(max_rows, n)
         # the framebuffer lives in a torch tensor so RCCL can move it; okrt renders straight into it, on torch's stream
-        accum_t = torch.zeros((max_rows, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-        result_t = torch.zeros((max_rows, W), dtype=torch.int32, device=f"cuda:{local_rank}")
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        accum_t = torch.zeros((max_rows, W, 4), dtype=torch.float32, device=f"cuda:{device_index}")
+        result_t = torch.zeros((max_rows, W), dtype=torch.int32, device=f"cuda:{device_index}")
+        # one explicit (non-null) stream for both the kernels and the collective: stream order replaces host syncs
+        work_stream = torch.cuda.Stream(device=device_index)
+        torch.cuda.set_stream(work_stream)
+        ctx.set_stream(work_stream.cuda_stream)
         ctx.bind_framebuffers(accum_t.data_ptr(), result_t.data_ptr())
         if rank == 0:
-            gathered = [torch.empty_like(accum_t) for _ in range(world)]
+            gathered = [torch.empty_like(accum_t if backend == "nccl" else accum_t.cpu()) for _ in range(world)]
 
     def gather_tiles():
         if world > 1:
-            dist.gather(accum_t, gathered if rank == 0 else None, dst=0)
+            src = accum_t if backend == "nccl" else accum_t.cpu()
+            dist.gather(src, gathered if rank == 0 else None, dst=0)
 
     def sync():
         if world > 1:
@@ -195,22 +215,28 @@ def main():
 
     rays_total, elapsed_max = rays_local, elapsed
     if world > 1:
-        t = torch.tensor([float(rays_local), 0.0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        red_dev = f"cuda:{device_index}" if backend == "nccl" else "cpu"
+        t = torch.tensor([float(rays_local), 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         rays_total = int(t[0].item())
-        tm = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tm = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         elapsed_max = float(tm.item())
-        ref_t = torch.tensor([float(ref_counters[k]) for k in sorted(ref_counters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        ref_t = torch.tensor([float(ref_counters[k]) for k in sorted(ref_counters)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ref_t, op=dist.ReduceOp.SUM)
         ref_counters = {k: int(v) for k, v in zip(sorted(ref_counters), ref_t.tolist())}
-        fast_t = torch.tensor([float(fast_counters[k]) for k in sorted(fast_counters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        fast_t = torch.tensor([float(fast_counters[k]) for k in sorted(fast_counters)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(fast_t, op=dist.ReduceOp.SUM)
         fast_counters = {k: int(v) for k, v in zip(sorted(fast_counters), fast_t.tolist())}
-        st = torch.tensor([trace_ms, shade_ms, other_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+        st = torch.tensor([trace_ms, shade_ms, other_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
         trace_ms, shade_ms, other_ms = st.tolist()
 
+    if rank == 0 and world > 1:
+        tiling = importlib.import_module("gpu-raytracer_amd.tiling")
+        full = tiling.deinterleave(gathered, H, STRIPE_ROWS)
+        frames_done = args.warmup + args.steps
+        assert bool((full[..., 3] == frames_done).all()), "gathered frame: accumulation alpha != number of frames"
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
         mrays = rays_total / elapsed_max / 1e6
@@ -218,18 +244,22 @@ def main():
         frames = max(timed_frames, 1)
         trace_ms_frame = trace_ms / frames
         achieved = trav_bytes / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0  # GB/s, whole frame's traversal
-        # what the kernel's OWN algorithm has to move per frame: 128 B per Node4 visit, 48 B per Tri48 test,
-        # 20 B hit record per ray, 32 B queue read per secondary ray (okrt_fast.h)
-        own_bytes = (128 * fast_counters["fast_nodes"] + 48 * fast_counters["fast_tris"] + 20 * fast_counters["segments"]
-                     + 32 * (fast_counters["segments"] - fast_counters["pixels"]))
-        own_achieved = own_bytes / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
+        # what the kernel's OWN algorithm has to move per frame: 64 B per Node4Q visit, 48 B per Tri48 test, 32 B ray read
+        # + 20 B hit record per ray, 32 B camera-ray write per pixel (okrt_fast.h)
+        own_bytes = (64 * fast_counters["fast_nodes"] + 48 * fast_counters["fast_tris"] + 52 * fast_counters["segments"]
+                     + 32 * fast_counters["pixels"])
+        # per GPU: every rank traces 1/world of the frame; the stage time is the slowest rank's
+        trav_bytes_gpu, own_bytes_gpu = trav_bytes / world, own_bytes / world
+        achieved = trav_bytes_gpu / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
+        own_achieved = own_bytes_gpu / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps,
                        "tile_split": f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks" if world > 1 else "full frame",
-                       "gather": f"RCCL gather of float4 tiles to rank 0 every {GATHER_EVERY} frames + final" if world > 1 else "none"},
+                       "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "
+                                  f"every {GATHER_EVERY} frames + final") if world > 1 else "none"},
             "roofline": {
                 "bound": "hbm", "kernel": "traceKernel (BVH traversal, primary + queued launches of one frame)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -239,9 +269,9 @@ def main():
                 "other_ms_per_frame": round(other_ms / frames, 4),
                 "kernel_own_bytes_per_frame": own_bytes, "kernel_own_achieved": round(own_achieved, 1),
                 "kernel_own_frac": round(own_achieved / HBM_PEAK_GBS, 4),
-                "node4_visits_per_ray": round(fast_counters["fast_nodes"] / max(fast_counters["segments"], 1), 2),
+                "node4q_visits_per_ray": round(fast_counters["fast_nodes"] / max(fast_counters["segments"], 1), 2),
                 "tri48_tests_per_ray": round(fast_counters["fast_tris"] / max(fast_counters["segments"], 1), 2),
-                "frame_frac": round((trav_bytes + shade_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frame_frac": round((trav_bytes + shade_bytes) / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "algorithmic bytes = what the REFERENCE's octree->mesh->BVH traversal order touches for the same rays "
                         "(SURVEY.md 8d); the derived BVH4 visits far fewer, so frac may exceed 1. kernel_own_* prices the "
                         "bytes the fast kernel's own node/triangle visits move (mostly L2/Infinity-Cache hits, see traffic)"},

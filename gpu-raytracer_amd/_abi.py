@@ -122,7 +122,10 @@ _device = None
 
 
 def load_device_library():
-    """Load libokrt.so (the HIP product). Raises if it is not built; never falls back."""
+    """Load libokrt.so (the HIP product). Raises if it is not built; never falls back.
+
+    In a process that also uses PyTorch, `import torch` FIRST: torch ships its own libamdhip64.so.7 and the dynamic
+    loader then binds libokrt.so to that same runtime instance (needed to share device pointers / streams)."""
     global _device
     if _device is None:
         path = device_library_path()

@@ -182,21 +182,31 @@ extern "C" {
 
 int okrt_abi_version(void) { return OKRT_ABI_VERSION; }
 
+static thread_local std::string g_createError;  // okrt_last_error(NULL): why the last okrt_create on this thread failed
+
 okrt_status okrt_create(int device, okrt_ctx** out) {
     if (!out) return OKRT_ERR_INVALID_ARG;
     *out = nullptr;
+    g_createError.clear();
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return OKRT_ERR_DEVICE;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device < 0 || device >= n) {
+        g_createError = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e)
+                                        : "device " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)";
+        return OKRT_ERR_DEVICE;
+    }
     okrt_ctx* c = new okrt_ctx();
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) {
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess) {
+        g_createError = std::string("hipSetDevice/hipStreamCreate: ") + hipGetErrorString(e);
         delete c;
         return OKRT_ERR_DEVICE;
     }
     c->stream = c->ownStream;
     hipEventCreate(&c->evBegin);
     hipEventCreate(&c->evEnd);
-    if (hipMalloc(&c->counters.ptr, kNumCounters * sizeof(unsigned long long)) != hipSuccess) {
+    if ((e = hipMalloc(&c->counters.ptr, kNumCounters * sizeof(unsigned long long))) != hipSuccess) {
+        g_createError = std::string("hipMalloc: ") + hipGetErrorString(e);
         delete c;
         return OKRT_ERR_OOM;
     }
@@ -224,7 +234,7 @@ okrt_status okrt_destroy(okrt_ctx* c) {
     return OKRT_OK;
 }
 
-const char* okrt_last_error(const okrt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* okrt_last_error(const okrt_ctx* c) { return c ? c->err.c_str() : g_createError.c_str(); }
 
 okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint32_t elem_bytes, uint32_t count) {
     if (!c) return OKRT_ERR_INVALID_ARG;

@@ -49,7 +49,7 @@ RayTracer::RayTracer(const okrt_api* api, int device) : m_api(api) {
     }
     okrt_status s = api->create(device, &m_ctx);
     if (s != OKRT_OK) {
-        m_error = "okrt create failed";
+        m_error = std::string("okrt create failed (status ") + std::to_string((int)s) + "): " + api->last_error(nullptr);
         m_ctx = nullptr;
     }
 }

@@ -151,7 +151,7 @@ typedef struct okrt_counters {
 int okrt_abi_version(void);
 okrt_status okrt_create(int device, okrt_ctx** out_ctx);
 okrt_status okrt_destroy(okrt_ctx* ctx);
-const char* okrt_last_error(const okrt_ctx* ctx); /* never NULL; "" when no error */
+const char* okrt_last_error(const okrt_ctx* ctx); /* never NULL; "" when no error; ctx == NULL: why the last okrt_create failed */
 
 /* ---- scene upload (the Scene->Graphics interface) ------------------------------------------ */
 /* Replace a whole table. `elem_bytes` must equal the slot's reference stride. count==0 or
