@@ -8,7 +8,7 @@ for cfg in "$@"; do
 import csv, glob, re
 for f in glob.glob("$out/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(traceKernel<\w+, \w+>|shadeKernel<\w+, \w+>)", r["Name"])
-        if m and "true>" not in m.group(1): print("   %-28s calls %4s avg_us %9.1f" % (m.group(1), r["Calls"], float(r["AverageNs"])/1e3))
+        m = re.search(r"(traceKernel<\w+>|shadeKernel<\w+, \w+>|generateKernel)", r["Name"])
+        if m and not m.group(1).endswith("true>"): print("   %-28s calls %4s avg_us %9.1f" % (m.group(1), r["Calls"], float(r["AverageNs"])/1e3))
 PY
 done

@@ -16,13 +16,13 @@ run tccB TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_
 python3 - <<PY
 import csv, glob, collections, re
 def short(name):
-    m = re.search(r"(traceKernel<\w+, \w+>|shadeKernel<\w+, \w+>|renderReferenceOrder)", name)
+    m = re.search(r"(traceKernel<\w+>|shadeKernel<\w+, \w+>|generateKernel|renderReferenceOrder)", name)
     return m.group(1) if m else None
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if k and "true>" not in k: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if k and not k.endswith("true>"): agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as out:
     for k in sorted(agg):
         out.write(k + "\n")

@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, re, sys
 
 
 def short(name):
-    m = re.search(r"(traceKernel<\w+, \w+>|shadeKernel<\w+, \w+>|renderReferenceOrder|scaleTextureKernel|__amd_rocclr_\w+)", name)
+    m = re.search(r"(traceKernel<\w+>|shadeKernel<\w+, \w+>|generateKernel|renderReferenceOrder|scaleTextureKernel|__amd_rocclr_\w+)", name)
     return m.group(1) if m else name[:40]
 
 
