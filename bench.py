@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="consecutive frames traced by one set of kernel launches (okrt_render_frames); 0 = auto")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,6 +149,9 @@ def main():
     ctx = rt.ctx
     ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
 
+    if world == 1 and os.environ.get("OKRT_BENCH_TILE"):  # developer knob: time one rank's share of an N-way split on 1 GPU
+        sr, si, ss = (int(v) for v in os.environ["OKRT_BENCH_TILE"].split(","))
+        ctx.set_tile(sr, si, ss)
     accum_t = gathered = None
     if world > 1:
         ctx.set_tile(STRIPE_ROWS, rank, world)
@@ -196,22 +201,42 @@ def main():
         rt.resetAccumulation()
 
     # ---- warm-up, then exactly K timed steps ----------------------------------------------------
-    for _ in range(args.warmup):
-        rt.render()
+    # A step is one frame. Frames are handed to the device layer F at a time (okrt_render_frames): same framebuffers
+    # bit for bit, but one set of kernel launches traces F frames' rays, which amortises the per-launch latency floor
+    # (the longest ray's dependent steps) — decisive when a rank only owns 1/N of the pixels.
+    fpl = args.frames_per_launch or int(os.environ.get("OKRT_BENCH_FPL", "0")) or 16
+    fpl = max(1, min(fpl, 16, GATHER_EVERY))
+
+    def run_frames(n, gather):
+        done = 0
+        while done < n:
+            m = min(fpl, n - done, GATHER_EVERY - done % GATHER_EVERY)
+            rt.renderFrames(m)
+            done += m
+            if gather and done % GATHER_EVERY == 0 and done != n:
+                gather_tiles()
+
+    run_frames(args.warmup, False)
     sync()
     ctx.reset_counters()
     ctx.set_option(abi.OPT_TIMING, args.steps)  # HIP events around every kernel, on the stream they run on
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        rt.render()
-        if (k + 1) % GATHER_EVERY == 0 and k + 1 != args.steps:
-            gather_tiles()
+    run_frames(args.steps, True)
     gather_tiles()
     sync()
     elapsed = time.perf_counter() - t0
     trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
     ctx.set_option(abi.OPT_TIMING, 0)
     rays_local = ctx.counters()["segments"]
+    # for reference: the same frames issued one okrt_render call per frame (the reference's main-loop shape)
+    single_ms = None
+    if world == 1:
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(16):
+            rt.render()
+        ctx.synchronize()
+        single_ms = (time.perf_counter() - t1) * 1e3 / 16
 
     rays_total, elapsed_max = rays_local, elapsed
     if world > 1:
@@ -256,7 +281,7 @@ def main():
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps,
+            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl, "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
                        "tile_split": f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks" if world > 1 else "full frame",
                        "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "
                                   f"every {GATHER_EVERY} frames + final") if world > 1 else "none"},

@@ -67,6 +67,7 @@ SIGNATURES = {
     "tile_rows": (C.c_int, [P, C.POINTER(U32)]),
     "reset_accumulation": (C.c_int, [P]),
     "render": (C.c_int, [P, C.POINTER(RenderData)]),
+    "render_frames": (C.c_int, [P, C.POINTER(RenderData), U32]),
     "synchronize": (C.c_int, [P]),
     "read_result_rgba8": (C.c_int, [P, P]),
     "read_accum_f32x4": (C.c_int, [P, P]),

@@ -51,7 +51,7 @@ struct okrt_ctx {
     bool fastDirty = true;
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
     // OKRT_OPT_TIMING: ring of per-render event lists (kernel boundaries, in launch order)
-    struct TimedFrame { std::vector<hipEvent_t> ev; int used = 0; bool fast = false; };
+    struct TimedFrame { std::vector<hipEvent_t> ev; int used = 0; bool fast = false; uint32_t frames = 1; };
     std::vector<TimedFrame> ring;
     size_t ringNext = 0, ringCount = 0;
     std::string err;
@@ -361,7 +361,26 @@ okrt_status okrt_reset_accumulation(okrt_ctx* c) {
     return OKRT_OK;
 }
 
-okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
+static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames);
+
+okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) { return renderImpl(c, rd, 1); }
+
+okrt_status okrt_render_frames(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
+    if (!c || !rd) return OKRT_ERR_INVALID_ARG;
+    if (!frames) return OKRT_OK;
+    const bool batchable = c->traversal == OKRT_TRAVERSAL_FAST && rd->debugMode == 0 && rd->accumulationEnabled == 1;
+    okrt_render_data cur = *rd;
+    while (frames) {
+        const uint32_t n = batchable ? std::min<uint32_t>(frames, kMaxFramesPerLaunch) : 1u;
+        okrt_status s = renderImpl(c, &cur, n);
+        if (s != OKRT_OK) return s;
+        if (cur.accumulationEnabled == 1) cur.numAccumulationFrames += n;  // the host's pre-increment per frame (RayTracer.cpp:489)
+        frames -= n;
+    }
+    return OKRT_OK;
+}
+
+static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
     if (!c->W) return fail(c, OKRT_ERR_STATE, "render before resize");
     if (rd->textureDims[0] != c->W || rd->textureDims[1] != c->H) return fail(c, OKRT_ERR_INVALID_ARG, "render: textureDims differ from the resize dimensions");
@@ -392,6 +411,7 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
             tf->ev.push_back(e);
         }
         tf->used = 0;
+        tf->frames = frames;
     }
     // The debug heat maps count the REFERENCE traversal's box/triangle checks (RaytracerCS.hlsl:516-520),
     // so those frames always run the reference-order kernel.
@@ -421,7 +441,7 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
         }
         std::string msg;
         if (!launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, (unsigned long long*)c->counters.ptr, c->stream,
-                        tf ? tf->ev.data() : nullptr, msg))
+                        tf ? tf->ev.data() : nullptr, frames, msg))
             return fail(c, OKRT_ERR_OOM, "fast pipeline: " + msg);
         if (tf) {
             tf->used = 2 * (c->maxBounces + 1) + 1;
@@ -563,7 +583,7 @@ okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames
         okrt_status s = frameStages(c, c->ring[i], st);
         if (s != OKRT_OK) return s;
         for (int k = 0; k < 3; ++k) out_ms[k] += st[k];
-        *out_frames += 1;
+        *out_frames += c->ring[i].frames;
     }
     return OKRT_OK;
 }
@@ -573,7 +593,7 @@ const okrt_api* okrt_get_api(void) {
                                  okrt_set_table,       okrt_set_textures,  okrt_set_envmap,   okrt_scale_texture_rgba8,
                                  okrt_resize,          okrt_set_tile,      okrt_tile_rows,    okrt_reset_accumulation,
                                  okrt_render,          okrt_synchronize,   okrt_read_result_rgba8, okrt_read_accum_f32x4,
-                                 okrt_set_option,      okrt_get_counters,  okrt_reset_counters};
+                                 okrt_set_option,      okrt_get_counters,  okrt_reset_counters, okrt_render_frames};
     return &api;
 }
 

@@ -404,8 +404,9 @@ OKRT_DEV void addLights(const SceneView& s, const okrt_render_data& rd, const Ra
 }
 
 // ---- camera (RaytracerCS.hlsl:177-216, 430) ------------------------------------------------------------------
-OKRT_DEV Ray primaryRay(const okrt_render_data& rd, uint32_t px, uint32_t py, uint32_t& seed) {
-    seed = px + (py + 74813u) * rd.textureDims[0] * (rd.numAccumulationFrames + 1u);  // :430
+// `frameN` = numAccumulationFrames of the frame this sample belongs to (rd's own value for a single frame).
+OKRT_DEV Ray primaryRay(const okrt_render_data& rd, uint32_t frameN, uint32_t px, uint32_t py, uint32_t& seed) {
+    seed = px + (py + 74813u) * rd.textureDims[0] * (frameN + 1u);  // :430
     float posx = (float)px, posy = (float)(rd.textureDims[1] - py);                   // H - y (Q10)
     posx += randomFloat(seed) - 0.5f;
     posy += randomFloat(seed) - 0.5f;
@@ -430,6 +431,10 @@ OKRT_DEV Ray primaryRay(const okrt_render_data& rd, uint32_t px, uint32_t py, ui
     ray.origin = ray.origin + rayOffset;
     ray.direction = normalize(focusPoint - ray.origin);
     return ray;
+}
+
+OKRT_DEV Ray primaryRay(const okrt_render_data& rd, uint32_t px, uint32_t py, uint32_t& seed) {
+    return primaryRay(rd, rd.numAccumulationFrames, px, py, seed);
 }
 
 // One bounce of the path state after a hit (RaytracerCS.hlsl:495-513).

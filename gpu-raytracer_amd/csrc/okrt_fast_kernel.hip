@@ -86,15 +86,17 @@ OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t
 
 // Camera rays for every owned pixel, in tile order (position i <-> pixel by primaryPixel): origin, direction,
 // RNG state after the 4 camera draws, framebuffer offset. Padding positions (outside the image) get pix = kInvalid.
-__global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileView tile, RayQueue q, uint32_t total) {
+// With `frames` > 1 the positions of frame f follow those of frame f-1 and pix addresses the frame's radiance slot.
+__global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileView tile, RayQueue q, uint32_t perFrame, uint32_t frames) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    if (i >= perFrame * frames) return;
+    const uint32_t f = i / perFrame, ii = i - f * perFrame;
     uint32_t px, lrow, seed = 0, pix = kInvalid;
     Ray ray;
     ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
-    if (primaryPixel(tile, i, px, lrow)) {
-        ray = primaryRay(rd, px, tile.globalRow(lrow), seed);
-        pix = lrow * tile.W + px;
+    if (primaryPixel(tile, ii, px, lrow)) {
+        ray = primaryRay(rd, rd.numAccumulationFrames + f, px, tile.globalRow(lrow), seed);
+        pix = f * (tile.rows * tile.W) + lrow * tile.W + px;
     }
     q.a[i] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x);
     q.b[i] = make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix));
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileV
 
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
-                                                            HitBuffer hb, ShardView sv, uint32_t isCamera,
+                                                            HitBuffer hb, ShardView sv, uint32_t cameraFrames,
                                                             unsigned long long* counters, unsigned long long* rayTotals) {
     // (ref, entry distance) pairs, [entry][thread]; row kLdsStack is a dummy target for predicated-off pushes
     __shared__ uint2 sStack[kLdsStack + 1][kTraceThreads];
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
     uint2* myOverflow = fv.overflow + (size_t)(blockIdx.x * kTraceThreads + tid) * fv.overflowCap;
     if (!COUNT && blockIdx.x == 0 && tid == 0) {  // rays of this launch, always counted (okrt_counters.pixels / .segments)
         unsigned long long n = 0;
-        if (isCamera) n = (unsigned long long)tile.W * tile.rows;
+        if (cameraFrames) n = (unsigned long long)tile.W * tile.rows * cameraFrames;
         else for (uint32_t k = 0; k < kShards; ++k) n += sv.count(k);
-        if (isCamera) atomicAdd(&rayTotals[0], n);
+        if (cameraFrames) atomicAdd(&rayTotals[0], n);
         atomicAdd(&rayTotals[1], n);
     }
     // wave-uniform work-fetch state
@@ -384,7 +386,8 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
 template <bool FIRST, bool COUNT>
 __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data rd, TileView tile, RayQueue qIn, HitBuffer hb,
                                                   ShardView in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce,
-                                                  uint32_t lastBounce, float4* accum, uint32_t* result, unsigned long long* counters) {
+                                                  uint32_t lastBounce, float4* accum, uint32_t* result, float4* radiance,
+                                                  unsigned long long* counters) {
     // positions are [shard][cap]; cap is a multiple of 256, so a block (and a wave) never straddles shards
     const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const uint32_t shard = (blockIdx.x * 256) / in.cap;
@@ -426,7 +429,10 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
             scatter(sf, ray, contribution, light, seed);  // :495-513 (also on the last segment: emission is added here)
             alive = bounce < lastBounce;
         }
-        if (!alive) writePixel(rd, light, 0, 0, accum, result, pix);
+        if (!alive) {
+            if (radiance) radiance[pix] = make_float4(light.x, light.y, light.z, 1.f);  // several frames in flight: added in frame order later
+            else writePixel(rd, light, 0, 0, accum, result, pix);
+        }
     }
     // ballot compaction of the surviving paths into the next queue: ranks inside the wave by ballot, waves inside
     // the block through LDS, ONE atomic per block on the shard's counter (one per wave saturated the counter line)
@@ -459,6 +465,22 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
             if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
         }
     }
+}
+
+// Adds the radiance slots of `frames` frames to the accumulation IN FRAME ORDER and resolves with the last frame's
+// count: exactly what `frames` consecutive single-frame passes do (RaytracerCS.hlsl:526-536).
+__global__ __launch_bounds__(256) void accumulateKernel(okrt_render_data rd, uint32_t pixels, uint32_t frames, const float4* radiance,
+                                                       float4* accum, uint32_t* result) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= pixels) return;
+    float4 a = accum[p];
+    for (uint32_t f = 0; f < frames; ++f) {
+        const float4 r = radiance[(size_t)f * pixels + p];
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += 1.f;
+    }
+    accum[p] = a;
+    const float n = (float)(rd.numAccumulationFrames + frames - 1u);
+    result[p] = toUnorm8(a.x / n) | (toUnorm8(a.y / n) << 8) | (toUnorm8(a.z / n) << 16) | (toUnorm8(a.w / n) << 24);
 }
 
 template <class T>
@@ -494,6 +516,8 @@ struct FastScene {
     uint2* overflow = nullptr;
     uint32_t overflowCap = 0;
     int traceBlocks = 0;
+    float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
+    size_t radianceCap = 0;
 };
 
 bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std::string& err) {
@@ -532,7 +556,7 @@ bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std:
 
 void fastDestroy(FastScene* fs) {
     if (!fs) return;
-    for (void* p : {(void*)fs->nodes, (void*)fs->tris, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri})
+    for (void* p : {(void*)fs->nodes, (void*)fs->tris, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
         if (p) hipFree(p);
     for (RayQueue& q : fs->q)
         for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
@@ -541,8 +565,14 @@ void fastDestroy(FastScene* fs) {
 }
 
 bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
-                unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, std::string& err) {
-    const uint32_t total = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays incl. tile padding
+                unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
+                std::string& err) {
+    const uint32_t perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
+    if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)perFrame * frames > 0x7FFFFFFFull) {
+        err = "frames per launch out of range";
+        return false;
+    }
+    const uint32_t total = perFrame * frames;
     const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
     const size_t items = (size_t)cap * kShards;
     if (items > fs.capacity) {
@@ -551,6 +581,16 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
             if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return false;
         if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return false;
         fs.capacity = items;
+    }
+    const size_t pixels = (size_t)t.rows * t.W;
+    float4* radiance = nullptr;
+    if (frames > 1) {
+        if (pixels * frames > fs.radianceCap) {
+            hipStreamSynchronize(stream);
+            if (!devAlloc(&fs.radiance, pixels * frames, err)) return false;
+            fs.radianceCap = pixels * frames;
+        }
+        radiance = fs.radiance;
     }
     const uint32_t lastBounce = s.maxBounces;
     if (lastBounce + 2 > kMaxSegments) {
@@ -573,16 +613,18 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     };
     mark();
     // segment 0: camera rays into q[0] (a, b only), then the same trace kernel as every other segment
-    hipLaunchKernelGGL(generateKernel, sg, dim3(256), 0, stream, rd, t, fs.q[0], total);
+    hipLaunchKernelGGL(generateKernel, sg, dim3(256), 0, stream, rd, t, fs.q[0], perFrame, frames);
     if (cnt)
-        hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), 1u, counters, rayTotals);
+        hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
     else
-        hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), 1u, counters, rayTotals);
+        hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
     mark();
     if (cnt)
-        hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, counters);
+        hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
     else
-        hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, counters);
+        hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
+    if (lastBounce == 0 && radiance)
+        hipLaunchKernelGGL(accumulateKernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, rd, (uint32_t)pixels, frames, radiance, accum, result);
     mark();
     // segments 1..lastBounce: queue b lives in q[b & 1]
     for (uint32_t b = 1; b <= lastBounce; ++b) {
@@ -594,9 +636,11 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
             hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals);
         mark();
         if (cnt)
-            hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, counters);
+            hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, radiance, counters);
         else
-            hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, counters);
+            hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, radiance, counters);
+        if (b == lastBounce && radiance)
+            hipLaunchKernelGGL(accumulateKernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, rd, (uint32_t)pixels, frames, radiance, accum, result);
         mark();
     }
     return true;

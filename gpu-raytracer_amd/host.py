@@ -107,6 +107,9 @@ class Context:
     def render(self, rd):
         self._ck(self.fns.render(self.h, C.byref(rd)), "render")
 
+    def render_frames(self, rd, frames):
+        self._ck(self.fns.render_frames(self.h, C.byref(rd), frames), "render_frames")
+
     def synchronize(self):
         self._ck(self.fns.synchronize(self.h), "synchronize")
 
@@ -214,6 +217,7 @@ def host_library():
             "okh_raytracer_loadMeshAndBvhData": (C.c_int, [P, U32, U32]),
             "okh_raytracer_createOctTree": (C.c_int, [P, P, U32, U32]),
             "okh_raytracer_setScene": (None, [P, P]), "okh_raytracer_render": (C.c_int, [P]),
+            "okh_raytracer_renderFrames": (C.c_int, [P, U32]),
             "okh_raytracer_toggleAccumulation": (None, [P, C.c_int]), "okh_raytracer_resetAccumulation": (None, [P]),
             "okh_raytracer_getNumAccumulationFrames": (U32, [P]),
             "okh_raytracer_setDOF": (None, [P, C.c_float, C.c_float]), "okh_raytracer_onResize": (C.c_int, [P, U32, U32]),
@@ -340,6 +344,9 @@ class RayTracer:
 
     def render(self):
         self._ck(self.lib.okh_raytracer_render(self.h), "render")
+
+    def renderFrames(self, frames):
+        self._ck(self.lib.okh_raytracer_renderFrames(self.h, frames), "renderFrames")
 
     def toggleAccumulation(self, enable):
         self.lib.okh_raytracer_toggleAccumulation(self.h, int(bool(enable)))

@@ -96,6 +96,7 @@ int okh_raytracer_createOctTree(okh_raytracer* r, const okh_scene* s, uint32_t m
 }
 void okh_raytracer_setScene(okh_raytracer* r, const okh_scene* s) { r->rt.setScene(s->scene); }
 int okh_raytracer_render(okh_raytracer* r) { return r->rt.render() ? 1 : 0; }
+int okh_raytracer_renderFrames(okh_raytracer* r, uint32_t frames) { return r->rt.renderFrames(frames) ? 1 : 0; }
 void okh_raytracer_toggleAccumulation(okh_raytracer* r, int enable) { r->rt.toggleAccumulation(enable != 0); }
 void okh_raytracer_resetAccumulation(okh_raytracer* r) { r->rt.resetAccumulation(); }
 uint32_t okh_raytracer_getNumAccumulationFrames(const okh_raytracer* r) { return r->rt.getNumAccumulationFrames(); }

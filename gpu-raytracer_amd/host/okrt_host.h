@@ -55,6 +55,7 @@ int okh_raytracer_loadMeshAndBvhData(okh_raytracer*, uint32_t maxDepth, uint32_t
 int okh_raytracer_createOctTree(okh_raytracer*, const okh_scene*, uint32_t maxDepth, uint32_t maxLeafObjects);
 void okh_raytracer_setScene(okh_raytracer*, const okh_scene*);
 int okh_raytracer_render(okh_raytracer*);
+int okh_raytracer_renderFrames(okh_raytracer*, uint32_t frames);
 void okh_raytracer_toggleAccumulation(okh_raytracer*, int enable);
 void okh_raytracer_resetAccumulation(okh_raytracer*);
 uint32_t okh_raytracer_getNumAccumulationFrames(const okh_raytracer*);

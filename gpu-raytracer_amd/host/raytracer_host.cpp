@@ -175,6 +175,19 @@ bool RayTracer::render() {
     return check(m_api->render(m_ctx, &m_renderData), "render");
 }
 
+bool RayTracer::renderFrames(uint32_t frames) {
+    if (!frames) return true;
+    if (!m_ctx || !m_pScene) {
+        m_error = "render: no device context or scene";
+        return false;
+    }
+    calculateProjectionData();
+    if (!updateBuffers()) return false;  // numAccumulationFrames now holds the FIRST frame's index
+    if (!check(m_api->render_frames(m_ctx, &m_renderData, frames), "render_frames")) return false;
+    m_renderData.numAccumulationFrames += m_renderData.accumulationEnabled * (frames - 1);
+    return true;
+}
+
 void RayTracer::calculateProjectionData() {
     int camId = m_pScene ? m_pScene->firstCamera() : -1;
     if (camId < 0) return;

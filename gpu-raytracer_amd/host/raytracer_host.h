@@ -135,6 +135,9 @@ public:
     bool createOctTree(const Scene& scene, uint32_t maxDepth, uint32_t maxLeafObjects);  // RayTracer.cpp:523-704
     void setScene(const Scene& scene) { m_pScene = &scene; }
     bool render();                                                                    // RayTracer.cpp:219-260
+    // `frames` consecutive render() calls with an unchanged scene and camera, handed to the device layer as one
+    // okrt_render_frames (same framebuffers, bit for bit; not in the reference, whose main loop calls render() per frame)
+    bool renderFrames(uint32_t frames);
     void toggleAccumulation(bool enable) { m_renderData.accumulationEnabled = enable ? 1u : 0u; resetAccumulation(); }
     void resetAccumulation();                                                         // RayTracer.h:203-209
     uint32_t getNumAccumulationFrames() const { return m_renderData.numAccumulationFrames; }

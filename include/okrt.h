@@ -191,6 +191,12 @@ okrt_status okrt_reset_accumulation(okrt_ctx* ctx);
 /* ---- render + readback --------------------------------------------------------------------- */
 /* One frame = one sample per owned pixel; asynchronous on the context's stream. */
 okrt_status okrt_render(okrt_ctx* ctx, const okrt_render_data* rd);
+/* `frames` consecutive frames in one call: exactly what `frames` okrt_render calls with
+ * rd->numAccumulationFrames, +1, +2, ... would leave in the framebuffers (bit-identical), but traced by shared
+ * kernel launches — the progressive-accumulation loop of the reference (Application.cpp:106-128 calling
+ * RayTracer::render once per frame) without paying the per-frame latency floor. With accumulation disabled, a debug
+ * mode or the reference-order traversal it simply loops. */
+okrt_status okrt_render_frames(okrt_ctx* ctx, const okrt_render_data* rd, uint32_t frames);
 okrt_status okrt_synchronize(okrt_ctx* ctx);
 /* Owned rows only, packed: rows*W*4 bytes / rows*W*4 floats. Row 0 = top of the image. */
 okrt_status okrt_read_result_rgba8(okrt_ctx* ctx, uint8_t* dst);
@@ -239,6 +245,7 @@ typedef struct okrt_api {
     okrt_status (*set_option)(okrt_ctx*, okrt_option, int64_t);
     okrt_status (*get_counters)(okrt_ctx*, okrt_counters*);
     okrt_status (*reset_counters)(okrt_ctx*);
+    okrt_status (*render_frames)(okrt_ctx*, const okrt_render_data*, uint32_t);
 } okrt_api;
 
 const okrt_api* okrt_get_api(void);

@@ -915,6 +915,17 @@ okrt_status okrt_oracle_reset_counters(okrt_ctx* c) {
 }
 
 okrt_status okrt_oracle_synchronize(okrt_ctx*) { return OKRT_OK; }
+// `frames` consecutive frames = `frames` single-frame passes with the host's per-frame pre-increment (RayTracer.cpp:489)
+okrt_status okrt_oracle_render_frames(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
+    if (!c || !rd) return OKRT_ERR_INVALID_ARG;
+    okrt_render_data cur = *rd;
+    for (uint32_t f = 0; f < frames; ++f) {
+        okrt_status s = okrt_oracle_render(c, &cur);
+        if (s != OKRT_OK) return s;
+        if (cur.accumulationEnabled == 1) cur.numAccumulationFrames += 1;
+    }
+    return OKRT_OK;
+}
 static okrt_status oracle_create_dev(int, okrt_ctx** out) { return okrt_oracle_create(out); }
 // The oracle behind the same entry-point table as the product, so tests can drive the C++ host
 // layer (gpu-raytracer_amd/host) against it on a machine without a GPU.
@@ -923,7 +934,7 @@ const okrt_api* okrt_oracle_get_api(void) {
                                  okrt_oracle_set_table, okrt_oracle_set_textures, okrt_oracle_set_envmap, okrt_oracle_scale_texture_rgba8,
                                  okrt_oracle_resize, okrt_oracle_set_tile, okrt_oracle_tile_rows, okrt_oracle_reset_accumulation,
                                  okrt_oracle_render, okrt_oracle_synchronize, okrt_oracle_read_result_rgba8, okrt_oracle_read_accum_f32x4,
-                                 okrt_oracle_set_option, okrt_oracle_get_counters, okrt_oracle_reset_counters};
+                                 okrt_oracle_set_option, okrt_oracle_get_counters, okrt_oracle_reset_counters, okrt_oracle_render_frames};
     return &api;
 }
 

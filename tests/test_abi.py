@@ -26,10 +26,10 @@ def test_libokrt_exports_every_declared_entry_point():
 
 def test_api_table_is_complete():
     lib = C.CDLL(abi.device_library_path())
-    lib.okrt_get_api.restype = C.POINTER(C.c_void_p * 19)
+    lib.okrt_get_api.restype = C.POINTER(C.c_void_p * 20)
     table = lib.okrt_get_api().contents
     assert C.cast(C.pointer(table), C.POINTER(C.c_uint32)).contents.value == abi.OKRT_ABI_VERSION
-    assert all(table[i] for i in range(1, 19))  # 18 function pointers, none NULL
+    assert all(table[i] for i in range(1, 20))  # 19 function pointers, none NULL
 
 
 def test_layout_constants():

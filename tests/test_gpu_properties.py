@@ -181,3 +181,31 @@ def test_table_update_with_a_different_count_reallocates():
     same = (a == b).all(-1)
     assert same.mean() > 0.995
     rt.close()
+
+
+def test_render_frames_is_bit_identical_to_single_frames(sponza):
+    """okrt_render_frames(F) must leave exactly what F okrt_render calls leave (accumulation AND resolve)."""
+    rt = sponza
+    rt.resetAccumulation()
+    for _ in range(5):
+        rt.render()
+    seq_acc, seq_res = rt.ctx.read_accum(), rt.ctx.read_result()
+    rt.resetAccumulation()
+    rt.renderFrames(3)
+    rt.renderFrames(2)
+    assert rt.getNumAccumulationFrames() == 5
+    bat_acc, bat_res = rt.ctx.read_accum(), rt.ctx.read_result()
+    assert np.array_equal(seq_acc, bat_acc, equal_nan=True) and np.array_equal(seq_res, bat_res)
+    # also through a tile, with a batch longer than the internal cap (16) and with max_bounces = 0
+    rt.ctx.set_option(abi.OPT_MAX_BOUNCES, 0)
+    rt.ctx.set_tile(8, 1, 4)
+    rt.resetAccumulation()
+    for _ in range(19):
+        rt.render()
+    a = rt.ctx.read_accum()
+    rt.resetAccumulation()
+    rt.renderFrames(19)
+    b = rt.ctx.read_accum()
+    rt.ctx.set_tile(1080, 0, 1)
+    rt.ctx.set_option(abi.OPT_MAX_BOUNCES, 1)
+    assert np.array_equal(a, b, equal_nan=True) and (a[..., 3] == 19).all()
