@@ -86,6 +86,7 @@ PRODUCT_ONLY = {
     "timer_elapsed_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "last_render_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "get_stage_ms": (C.c_int, [P, C.POINTER(C.c_float * 3), C.POINTER(U32)]),
+    "write_accum_f32x4": (C.c_int, [P, P]),
     "get_api": (P, []),
 }
 HEADER_SYMBOLS = ["okrt_" + n for n in list(SIGNATURES) + list(PRODUCT_ONLY)]

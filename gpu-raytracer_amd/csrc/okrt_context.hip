@@ -478,6 +478,15 @@ okrt_status okrt_read_accum_f32x4(okrt_ctx* c, float* dst) {
     return OKRT_OK;
 }
 
+okrt_status okrt_write_accum_f32x4(okrt_ctx* c, const float* src) {
+    if (!c || !src) return OKRT_ERR_INVALID_ARG;
+    if (!c->accum) return fail(c, OKRT_ERR_STATE, "write before resize");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    OKRT_HIP(c, hipMemcpyAsync(c->accum, src, (size_t)c->tile.rows * c->W * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    return OKRT_OK;
+}
+
 okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
     if (!c) return OKRT_ERR_INVALID_ARG;
     switch (opt) {

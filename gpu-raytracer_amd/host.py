@@ -118,6 +118,11 @@ class Context:
         self._ck(self.fns.read_accum_f32x4(self.h, _ptr(out)), "read_accum")
         return out
 
+    def write_accum(self, accum):
+        a = np.ascontiguousarray(accum, dtype=np.float32)
+        assert a.shape == (self.tile_rows(), self.W, 4)
+        self._ck(self.fns.write_accum_f32x4(self.h, _ptr(a)), "write_accum")
+
     def read_result(self):
         out = np.empty((self.tile_rows(), self.W, 4), dtype=np.uint8)
         self._ck(self.fns.read_result_rgba8(self.h, _ptr(out)), "read_result")
@@ -204,6 +209,7 @@ def host_library():
             "okh_material_default": (None, [P]),
             "okh_resources_create": (P, []), "okh_resources_destroy": (None, [P]),
             "okh_resources_add_mesh": (U32, [P, P, P, U32]), "okh_resources_add_texture": (U32, [P, P, U32, U32]),
+            "okh_resources_import_obj": (C.c_int, [P, C.c_char_p, C.c_float, C.c_char_p, U32]),
             "okh_scene_create": (P, []), "okh_scene_destroy": (None, [P]), "okh_scene_create_entity": (U32, [P]),
             "okh_scene_set_transform": (None, [P, U32, F3, F3, F3]),
             "okh_scene_add_mesh": (None, [P, U32, U32, P]), "okh_scene_add_sphere": (None, [P, U32, C.c_float, P]),
@@ -258,6 +264,16 @@ class ResourceManager:
     def add_texture(self, rgba8):
         a = np.ascontiguousarray(rgba8, dtype=np.uint8)
         return self.lib.okh_resources_add_texture(self.h, _ptr(a), a.shape[1], a.shape[0])
+
+    def import_obj(self, path, scale=1.0):
+        """ResourceManager::importAssets for OBJ/MTL: returns [{name, meshId, numTris, albedo, roughness, metallic,
+        specular, normal}] (texture entries are the file names of the .mtl; decode + add_texture them yourself)."""
+        import json
+        buf = C.create_string_buffer(1 << 22)
+        n = self.lib.okh_resources_import_obj(self.h, os.fsencode(path), float(scale), buf, len(buf))
+        if n < 0:
+            raise OkrtError("import_obj: " + buf.value.decode(errors="replace"))
+        return json.loads(buf.value.decode())
 
     def __del__(self):
         if getattr(self, "h", None):

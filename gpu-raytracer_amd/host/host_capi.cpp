@@ -1,6 +1,9 @@
 // host_capi.cpp — flat C view of the host layer (okrt_host.h).
 #include <cstring>
 
+#include <string>
+
+#include "obj_loader.h"
 #include "okrt_host.h"
 #include "raytracer_host.h"
 
@@ -32,6 +35,45 @@ uint32_t okh_resources_add_mesh(okh_resources* r, const float* positions, const 
     return r->rm.addMesh(positions, info, numTris);
 }
 uint32_t okh_resources_add_texture(okh_resources* r, const uint8_t* rgba8, uint32_t w, uint32_t h) { return r->rm.addTexture(rgba8, w, h); }
+
+int okh_resources_import_obj(okh_resources* r, const char* filePath, float scale, char* json, uint32_t cap) {
+    std::vector<okh::ObjObject> objs;
+    std::string err;
+    auto put = [&](const std::string& s) {
+        if (json && cap) {
+            std::strncpy(json, s.c_str(), cap - 1);
+            json[cap - 1] = 0;
+        }
+    };
+    if (!okh::loadObjects(filePath, objs, scale, err)) {
+        put(err);
+        return -1;
+    }
+    auto esc = [](const std::string& s) {
+        std::string o;
+        for (char c : s) {
+            if (c == '"' || c == '\\') o += '\\';
+            o += c;
+        }
+        return o;
+    };
+    std::string out = "[";
+    for (size_t i = 0; i < objs.size(); ++i) {
+        const okh::ObjObject& o = objs[i];
+        uint32_t id = r->rm.addMesh((const float*)o.positions.data(), (const float*)o.info.data(), (uint32_t)o.positions.size());
+        out += std::string(i ? "," : "") + "{\"name\":\"" + esc(o.name) + "\",\"meshId\":" + std::to_string(id) + ",\"numTris\":" +
+               std::to_string(o.positions.size()) + ",\"albedo\":\"" + esc(o.albedoTexturePath) + "\",\"roughness\":\"" + esc(o.roughnessTexturePath) +
+               "\",\"metallic\":\"" + esc(o.metallicTexturePath) + "\",\"specular\":\"" + esc(o.specularTexturePath) + "\",\"normal\":\"" +
+               esc(o.normalTexturePath) + "\"}";
+    }
+    out += "]";
+    if (out.size() + 1 > cap) {
+        put("json buffer too small");
+        return -1;
+    }
+    put(out);
+    return (int)objs.size();
+}
 
 okh_scene* okh_scene_create(void) { return new okh_scene(); }
 void okh_scene_destroy(okh_scene* s) { delete s; }

@@ -70,6 +70,12 @@ int okh_raytracer_updateBuffers(okh_raytracer*);
 /* which: the okrt_table slot numbers; 100 = MeshDesc (16 B), 3 = scaled texture array (elem = side) */
 int okh_raytracer_table(const okh_raytracer*, uint32_t which, const void** data, uint32_t* count, uint32_t* elemBytes);
 
+/* ResourceManager::importAssets (ResourceManager.cpp:44-81) for Wavefront OBJ/MTL: one mesh per object, appended to
+ * `res`. Writes a JSON array describing the objects into `json` (name, meshId, numTris and the five texture file
+ * names as the .mtl gives them; the caller decodes images and calls okh_resources_add_texture, which keeps the C++
+ * layer free of an image decoder). Returns the number of objects, or -1 (message in `json`). */
+int okh_resources_import_obj(okh_resources*, const char* filePath, float scale, char* json, uint32_t jsonCapacity);
+
 /* standalone pieces for tests */
 /* returns node count; nodes36/triOrder may be NULL to size */
 uint32_t okh_bvh_build(const float* tris9, uint32_t numTris, uint32_t maxLeafTriangles, uint32_t maxDepth,

@@ -570,3 +570,37 @@ def instantiate(desc, width, height, device=0, api=None, fns=None, host=None):
     rt.setScene(scene)
     rt.createOctTree(scene, *desc.octree)
     return rt, scene, res
+
+
+def load_meshes_as_entities(resources, scene, file_path, textures_path="", scale=1.0, host=None):
+    """Application::loadMeshesAsEntities (Application.cpp:131-152) for OBJ/MTL files: imports the objects, loads the
+    textures the materials name (deduplicated by file name like ResourceManager::findOrLoadTexture), and creates one
+    entity per object with its texture ids wired into the material. Returns the object descriptions."""
+    import os
+    from PIL import Image
+    if host is None:
+        from . import host as host_mod
+    else:
+        host_mod = host
+    objs = resources.import_obj(file_path, scale)
+    loaded = getattr(resources, "_texture_ids", None)
+    if loaded is None:
+        loaded = resources._texture_ids = {}
+
+    def tex(name):
+        if not name:
+            return 0xFFFFFFFF
+        key = os.path.basename(name.replace("\\\\", "/"))
+        if key not in loaded:
+            path = os.path.join(textures_path, name) if textures_path else os.path.join(os.path.dirname(file_path), name)
+            img = np.asarray(Image.open(path).convert("RGBA"), dtype=np.uint8)  # stbi_load(..., STBI_rgb_alpha)
+            loaded[key] = resources.add_texture(img)
+        return loaded[key]
+
+    for o in objs:
+        ent = scene.create_entity()
+        mat = host_mod.Material(albedoTextureId=tex(o["albedo"]), roughnessTextureId=tex(o["roughness"]), metallicTextureId=tex(o["metallic"]),
+                                specularTextureId=tex(o["specular"]), normalMapIdx=tex(o["normal"]))
+        scene.add_mesh(ent, o["meshId"], mat)
+        o["entity"] = ent
+    return objs

@@ -201,6 +201,10 @@ okrt_status okrt_synchronize(okrt_ctx* ctx);
 /* Owned rows only, packed: rows*W*4 bytes / rows*W*4 floats. Row 0 = top of the image. */
 okrt_status okrt_read_result_rgba8(okrt_ctx* ctx, uint8_t* dst);
 okrt_status okrt_read_accum_f32x4(okrt_ctx* ctx, float* dst);
+/* Restore a float accumulation saved with okrt_read_accum_f32x4 (owned rows, packed): together with the host's
+ * numAccumulationFrames this resumes a long progressive render ("checkpoint / resume"; the reference
+ * has none). */
+okrt_status okrt_write_accum_f32x4(okrt_ctx* ctx, const float* src);
 
 /* ---- options, counters, timing ------------------------------------------------------------- */
 okrt_status okrt_set_option(okrt_ctx* ctx, okrt_option opt, int64_t value);

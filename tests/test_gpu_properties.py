@@ -209,3 +209,22 @@ def test_render_frames_is_bit_identical_to_single_frames(sponza):
     rt.ctx.set_tile(1080, 0, 1)
     rt.ctx.set_option(abi.OPT_MAX_BOUNCES, 1)
     assert np.array_equal(a, b, equal_nan=True) and (a[..., 3] == 19).all()
+
+
+def test_checkpoint_resume_is_bit_identical():
+    """Save the float accumulation + the host's frame counter after 3 frames, restore into a fresh context, render 2
+    more: identical to 5 uninterrupted frames."""
+    desc = scenes.small_mesh_scene(seed=6, n_objects=4, detail=6)
+    rt, sc, res = scenes.instantiate(desc, 96, 54)
+    rt.renderFrames(5)
+    full = rt.ctx.read_accum()
+    rt.resetAccumulation()
+    rt.renderFrames(3)
+    saved, n = rt.ctx.read_accum(), rt.getNumAccumulationFrames()
+    rt.close()
+    rt2, sc2, res2 = scenes.instantiate(desc, 96, 54)
+    rt2.ctx.write_accum(saved)
+    rt2.render_data.numAccumulationFrames = n
+    rt2.renderFrames(2)
+    assert np.array_equal(rt2.ctx.read_accum(), full, equal_nan=True)
+    rt2.close()
