@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
+    ap.add_argument("--split", default="tiles", choices=["tiles", "samples"],
+                    help="N > 1: 'tiles' = image-space stripes + gather (the north-star path); 'samples' = every rank renders "
+                         "the whole frame for its own block of frame indices, accumulations are summed with one reduce")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="consecutive frames traced by one set of kernel launches (okrt_render_frames); 0 = auto")
     args = ap.parse_args()
@@ -153,13 +156,16 @@ def main():
         sr, si, ss = (int(v) for v in os.environ["OKRT_BENCH_TILE"].split(","))
         ctx.set_tile(sr, si, ss)
     accum_t = gathered = None
+    samples_split = world > 1 and args.split == "samples"
     if world > 1:
-        ctx.set_tile(STRIPE_ROWS, rank, world)
-        rows = ctx.tile_rows()
-        max_rows = 0
-        for r in range(world):  # every rank pads its tile to the largest one so gather sizes match
-            n = sum(min(STRIPE_ROWS, H - s * STRIPE_ROWS) for s in range(r, (H + STRIPE_ROWS - 1) // STRIPE_ROWS, world))
-            max_rows = max(max_rows, n)
+        if samples_split:
+            max_rows = H  # whole frame on every rank
+        else:
+            ctx.set_tile(STRIPE_ROWS, rank, world)
+            max_rows = 0
+            for r in range(world):  # every rank pads its tile to the largest one so gather sizes match
+                n = sum(min(STRIPE_ROWS, H - s * STRIPE_ROWS) for s in range(r, (H + STRIPE_ROWS - 1) // STRIPE_ROWS, world))
+                max_rows = max(max_rows, n)
         # the framebuffer lives in a torch tensor so RCCL can move it; okrt renders straight into it, on torch's stream
         accum_t = torch.zeros((max_rows, W, 4), dtype=torch.float32, device=f"cuda:{device_index}")
         result_t = torch.zeros((max_rows, W), dtype=torch.int32, device=f"cuda:{device_index}")
@@ -171,10 +177,21 @@ def main():
         if rank == 0:
             gathered = [torch.empty_like(accum_t if backend == "nccl" else accum_t.cpu()) for _ in range(world)]
 
-    def gather_tiles():
-        if world > 1:
-            src = accum_t if backend == "nccl" else accum_t.cpu()
-            dist.gather(src, gathered if rank == 0 else None, dst=0)
+    def gather_tiles(final=False):
+        if world <= 1:
+            return
+        if samples_split:  # disjoint frame indices, same pixels: one sum at the very end
+            if final:
+                if backend == "nccl":
+                    dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
+                else:
+                    host_acc = accum_t.cpu()
+                    dist.reduce(host_acc, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        gathered[0].copy_(host_acc)
+            return
+        src = accum_t if backend == "nccl" else accum_t.cpu()
+        dist.gather(src, gathered if rank == 0 else None, dst=0)
 
     def sync():
         if world > 1:
@@ -217,12 +234,18 @@ def main():
                 gather_tiles()
 
     run_frames(args.warmup, False)
+    steps_here = args.steps
+    if samples_split:  # rank r renders frame indices r*K/N + 1 ... (r+1)*K/N of a fresh accumulation
+        assert args.steps % world == 0, "--split samples needs steps divisible by the number of ranks"
+        steps_here = args.steps // world
+        rt.resetAccumulation()
+        rt.render_data.numAccumulationFrames = rank * steps_here
     sync()
     ctx.reset_counters()
     ctx.set_option(abi.OPT_TIMING, args.steps)  # HIP events around every kernel, on the stream they run on
     t0 = time.perf_counter()
-    run_frames(args.steps, True)
-    gather_tiles()
+    run_frames(steps_here, not samples_split)
+    gather_tiles(final=True)
     sync()
     elapsed = time.perf_counter() - t0
     trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
@@ -258,10 +281,14 @@ def main():
         trace_ms, shade_ms, other_ms = st.tolist()
 
     if rank == 0 and world > 1:
-        tiling = importlib.import_module("gpu-raytracer_amd.tiling")
-        full = tiling.deinterleave(gathered, H, STRIPE_ROWS)
-        frames_done = args.warmup + args.steps
-        assert bool((full[..., 3] == frames_done).all()), "gathered frame: accumulation alpha != number of frames"
+        if samples_split:
+            full = accum_t if backend == "nccl" else gathered[0]
+            frames_done = args.steps
+        else:
+            tiling = importlib.import_module("gpu-raytracer_amd.tiling")
+            full = tiling.deinterleave(gathered, H, STRIPE_ROWS)
+            frames_done = args.warmup + args.steps
+        assert bool((full[..., 3] == frames_done).all()), "combined frame: accumulation alpha != number of frames"
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
         mrays = rays_total / elapsed_max / 1e6
@@ -274,7 +301,8 @@ def main():
         own_bytes = (64 * fast_counters["fast_nodes"] + 48 * fast_counters["fast_tris"] + 52 * fast_counters["segments"]
                      + 32 * fast_counters["pixels"])
         # per GPU: every rank traces 1/world of the frame; the stage time is the slowest rank's
-        trav_bytes_gpu, own_bytes_gpu = trav_bytes / world, own_bytes / world
+        per_gpu = 1 if samples_split else world  # the counters come from each rank's own pixels
+        trav_bytes_gpu, own_bytes_gpu = trav_bytes / per_gpu / (world if samples_split else 1), own_bytes / per_gpu / (world if samples_split else 1)
         achieved = trav_bytes_gpu / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
         own_achieved = own_bytes_gpu / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
         out = {
@@ -282,7 +310,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl, "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
-                       "tile_split": f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks" if world > 1 else "full frame",
+                       "tile_split": ("samples split: every rank renders the whole frame for its own block of frame indices" if samples_split else
+                                      f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks") if world > 1 else "full frame",
                        "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "
                                   f"every {GATHER_EVERY} frames + final") if world > 1 else "none"},
             "roofline": {

@@ -51,13 +51,23 @@ def _rank_main(rank, world, port, out_path):
     buf[: tile.shape[0]] = torch.from_numpy(tile)
     gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, gathered, dst=0)
+    # samples split (bench.py --split samples): same pixels, disjoint frame indices, one SUM reduce
+    rt.ctx.set_tile(H, 0, 1)
+    rt.resetAccumulation()
+    rt.render_data.numAccumulationFrames = rank * 2  # rank r renders frames 2r+1, 2r+2
+    rt.renderFrames(2)
+    part = torch.from_numpy(rt.ctx.read_accum())
+    dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)
     if rank == 0:
         full = tiling.deinterleave(gathered, H, SR).numpy()
         ref_rt, _, _ = oracle.instantiate(desc, W, H)
         for _ in range(FRAMES):
             ref_rt.render()
         ref = ref_rt.ctx.read_accum()
-        np.save(out_path, np.array([np.array_equal(full, ref, equal_nan=True), float(np.nanmax(np.abs(full - ref)))]))
+        ref_rt.render()  # 4 frames = what the two ranks' sample blocks add up to
+        ref4 = ref_rt.ctx.read_accum()
+        samples_ok = bool(np.allclose(part.numpy(), ref4, rtol=1e-5, atol=1e-6, equal_nan=True) and (part.numpy()[..., 3] == 2 * world).all())
+        np.save(out_path, np.array([np.array_equal(full, ref, equal_nan=True) and samples_ok, float(np.nanmax(np.abs(full - ref)))]))
     dist.barrier()
     dist.destroy_process_group()
 
