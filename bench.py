@@ -98,8 +98,8 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])

@@ -34,7 +34,7 @@ struct okrt_ctx {
     int device = 0;
     hipStream_t ownStream = nullptr, stream = nullptr;
     Table tables[11];
-    DeviceBuffer textures, env;
+    DeviceBuffer textures, env, shadeInfo;
     uint32_t numTextures = 0, texW = 0, texH = 0, envFace = 0;
     uint32_t W = 0, H = 0;
     TileView tile{};
@@ -158,6 +158,7 @@ SceneView makeView(const okrt_ctx* c) {
     SceneView s{};
     s.triPos = (const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].dev.ptr;
     s.triInfo = (const TriangleInfoRec*)c->tables[OKRT_TABLE_TRI_INFO].dev.ptr;
+    s.shadeInfo = (const float4*)c->shadeInfo.ptr;
     s.bvh = (const BvhNodeRec*)c->tables[OKRT_TABLE_BVH].dev.ptr;
     s.textures = (const uint8_t*)c->textures.ptr;
     s.env = (const uint8_t*)c->env.ptr;
@@ -222,7 +223,7 @@ okrt_status okrt_destroy(okrt_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (Table& t : c->tables)
         if (t.dev.ptr) hipFree(t.dev.ptr);
-    for (DeviceBuffer* b : {&c->textures, &c->env, &c->accumOwn, &c->resultOwn, &c->counters})
+    for (DeviceBuffer* b : {&c->textures, &c->env, &c->shadeInfo, &c->accumOwn, &c->resultOwn, &c->counters})
         if (b->ptr) hipFree(b->ptr);
     fastDestroy(c->fast);
     for (hipEvent_t e : {c->evBegin, c->evEnd})
@@ -253,6 +254,23 @@ okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint3
     if (bytes) {
         // the previous contents may still be read by an in-flight frame on this stream: stream order
         OKRT_HIP(c, hipMemcpyAsync(t.dev.ptr, t.host.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if (slot == OKRT_TABLE_TRI_INFO) {  // derive the 64-byte shading records (okrt_device.h: SceneView::shadeInfo)
+        std::vector<float> packed((size_t)count * 16, 0.f);
+        const TriangleInfoRec* ti = (const TriangleInfoRec*)t.host.data();
+        for (uint32_t i = 0; i < count; ++i) {
+            float* o = &packed[(size_t)i * 16];
+            for (int v = 0; v < 3; ++v)
+                for (int k = 0; k < 3; ++k) o[4 * v + k] = ti[i].v[v].normal[k];
+            o[3] = ti[i].v[0].uv[0]; o[7] = ti[i].v[0].uv[1]; o[11] = ti[i].v[1].uv[0];
+            o[12] = ti[i].v[1].uv[1]; o[13] = ti[i].v[2].uv[0]; o[14] = ti[i].v[2].uv[1];
+        }
+        okrt_status s2 = ensure(c, c->shadeInfo, packed.size() * sizeof(float));
+        if (s2 != OKRT_OK) return s2;
+        if (!packed.empty()) {
+            OKRT_HIP(c, hipMemcpyAsync(c->shadeInfo.ptr, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            OKRT_HIP(c, hipStreamSynchronize(c->stream));  // `packed` dies at return
+        }
     }
     if (slot == OKRT_TABLE_TRI_POS || slot == OKRT_TABLE_TRI_INFO || slot == OKRT_TABLE_BVH || slot == OKRT_TABLE_OCT || slot == OKRT_TABLE_MESH) {
         c->tablesDirty = true;

@@ -58,6 +58,9 @@ static_assert(sizeof(OctNodeRec) == 48 && sizeof(DirLightRec) == 32 && sizeof(Po
 struct SceneView {
     const TriangleRec* triPos;          // t0
     const TriangleInfoRec* triInfo;     // t1
+    const float4* shadeInfo;            // derived from t1 at upload: 64 B per triangle = {n0,uv0.x} {n1,uv0.y} {n2,uv1.x} {uv1.y,uv2.x,uv2.y,-}:
+                                        // the normals + uvs every mesh hit needs in ONE aligned 64-byte read instead of a 132-byte
+                                        // unaligned record (tangent frames stay in t1: only normal-mapped hits read them)
     const BvhNodeRec* bvh;              // t2
     const uint8_t* textures;            // t3  count x texH x texW RGBA8
     const uint8_t* env;                 // t4  6 x face x face RGBA8
@@ -321,10 +324,13 @@ OKRT_DEV Surface shadeFetch(const SceneView& s, const Ray& ray, const Hit& h, Pa
         const MeshRec& mesh = s.meshes[h.hitIdx];
         const Material& m = mesh.material;
         const TriangleInfoRec& ti = s.triInfo[h.triIdx];
+        const float4* si = s.shadeInfo + (size_t)h.triIdx * 4;
+        const float4 r0 = si[0], r1 = si[1], r2 = si[2], r3 = si[3];
+        const float n0[3] = {r0.x, r0.y, r0.z}, n1[3] = {r1.x, r1.y, r1.z}, n2[3] = {r2.x, r2.y, r2.z};
         float bz = 1.f - (h.bu + h.bv);  // :324
-        float lu = fma_(ti.v[2].uv[0], bz, fma_(ti.v[1].uv[0], h.bv, ti.v[0].uv[0] * h.bu));
-        float lv = fma_(ti.v[2].uv[1], bz, fma_(ti.v[1].uv[1], h.bv, ti.v[0].uv[1] * h.bu));
-        V3 n = normalize(matDir(mesh.M, bary3(h.bu, h.bv, bz, ti.v[0].normal, ti.v[1].normal, ti.v[2].normal)));  // M*n, not inverse-transpose (Q11)
+        float lu = fma_(r3.y, bz, fma_(r2.w, h.bv, r0.w * h.bu));
+        float lv = fma_(r3.z, bz, fma_(r3.x, h.bv, r1.w * h.bu));
+        V3 n = normalize(matDir(mesh.M, bary3(h.bu, h.bv, bz, n0, n1, n2)));  // M*n, not inverse-transpose (Q11)
         if (m.normalMapIdx != kInvalid) {
             V3 tangent = normalize(matDir(mesh.M, bary3(h.bu, h.bv, bz, ti.v[0].tangent, ti.v[1].tangent, ti.v[2].tangent)));
             V3 bitangent = normalize(matDir(mesh.M, bary3(h.bu, h.bv, bz, ti.v[0].bitangent, ti.v[1].bitangent, ti.v[2].bitangent)));
