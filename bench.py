@@ -8,7 +8,7 @@ BASELINE.json's headline config (Sponza-class 1920x1080, configs[3]; procedural 
 262 267 triangles / 390 meshes / 26 textures). N > 1 (launched by
 torch.distributed.run): the SAME frame is split into interleaved 8-row stripes, rank r owns stripes
 r, r+N, ...; scene tables are replicated; there is no data-path collective per frame — the per-rank
-float4 accumulation tiles are gathered to rank 0 over RCCL every 16 frames and after the last one
+float4 accumulation tiles are gathered to rank 0 over RCCL every 64 frames and after the last one
 (inside the timed region). Total work is fixed, so "scaling" is "strong".
 
 The JSON line carries the roofline of the dominant kernel family (BVH traversal) and a CPU baseline
@@ -28,7 +28,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:36)
 STRIPE_ROWS = 8
-GATHER_EVERY = 16
+GATHER_EVERY = 64
 
 WORKLOADS = {
     # name: (scene builder kwargs, width, height, description)
@@ -221,19 +221,23 @@ def main():
     # A step is one frame. Frames are handed to the device layer F at a time (okrt_render_frames): same framebuffers
     # bit for bit, but one set of kernel launches traces F frames' rays, which amortises the per-launch latency floor
     # (the longest ray's dependent steps) — decisive when a rank only owns 1/N of the pixels.
-    fpl = args.frames_per_launch or int(os.environ.get("OKRT_BENCH_FPL", "0")) or 16
-    fpl = max(1, min(fpl, 16, GATHER_EVERY))
+    # default: 16 frames per launch set on one GPU; with N ranks each owns 1/N of the pixels, so 64 (= the gather period)
+    fpl = args.frames_per_launch or int(os.environ.get("OKRT_BENCH_FPL", "0")) or (16 if world == 1 else 64)
+    gather_every = int(os.environ.get("OKRT_BENCH_GATHER_EVERY", GATHER_EVERY))
+    fpl = max(1, min(fpl, 64, gather_every))
 
     def run_frames(n, gather):
         done = 0
         while done < n:
-            m = min(fpl, n - done, GATHER_EVERY - done % GATHER_EVERY)
+            m = min(fpl, n - done, gather_every - done % gather_every)
             rt.renderFrames(m)
             done += m
-            if gather and done % GATHER_EVERY == 0 and done != n:
+            if gather and done % gather_every == 0 and done != n:
                 gather_tiles()
 
     run_frames(args.warmup, False)
+    if args.warmup % fpl:  # also warm the buffers of a full-size launch set (untimed)
+        run_frames(fpl, False)
     steps_here = args.steps
     if samples_split:  # rank r renders frame indices r*K/N + 1 ... (r+1)*K/N of a fresh accumulation
         assert args.steps % world == 0, "--split samples needs steps divisible by the number of ranks"
@@ -244,7 +248,9 @@ def main():
     ctx.reset_counters()
     ctx.set_option(abi.OPT_TIMING, args.steps)  # HIP events around every kernel, on the stream they run on
     t0 = time.perf_counter()
+    ctx.timer_begin()
     run_frames(steps_here, not samples_split)
+    ctx.timer_end()
     gather_tiles(final=True)
     sync()
     elapsed = time.perf_counter() - t0
@@ -287,7 +293,7 @@ def main():
         else:
             tiling = importlib.import_module("gpu-raytracer_amd.tiling")
             full = tiling.deinterleave(gathered, H, STRIPE_ROWS)
-            frames_done = args.warmup + args.steps
+            frames_done = args.warmup + (fpl if args.warmup % fpl else 0) + args.steps
         assert bool((full[..., 3] == frames_done).all()), "combined frame: accumulation alpha != number of frames"
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
@@ -309,7 +315,7 @@ def main():
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl, "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
+            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl, "gpu_event_ms_per_step": round(ctx.timer_elapsed_ms() / max(steps_here, 1), 4), "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
                        "tile_split": ("samples split: every rank renders the whole frame for its own block of frame indices" if samples_split else
                                       f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks") if world > 1 else "full frame",
                        "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "

@@ -77,6 +77,6 @@ void fastDestroy(FastScene* scene);
 bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum,
                 uint32_t* result, unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events,
                 uint32_t frames, std::string& err);
-constexpr uint32_t kMaxFramesPerLaunch = 16;
+constexpr uint32_t kMaxFramesPerLaunch = 64;
 
 }  // namespace okrt
