@@ -177,3 +177,45 @@ def test_q22_octree_child_boxes_are_local_space(oracle):
     assert_1spp(ga_ref, ca)
     assert abs(gc_ref["mesh_hits"] - cc["mesh_hits"]) <= 8
     assert gc_fast["mesh_hits"] > cc["mesh_hits"] * 1.05  # the properly bounded structure finds MORE geometry
+
+
+def test_depth_of_field_and_accumulation_toggle(oracle):
+    """applyDOF with a non-zero lens (RaytracerCS.hlsl:208-216) and the accumulationEnabled == 0 branch (:531-534)."""
+    desc = scenes.small_mesh_scene(seed=12, n_objects=5, detail=8)
+    outs = []
+    for backend in ("gpu", "cpu"):
+        rt, sc, res = scenes.instantiate(desc, 160, 90) if backend == "gpu" else oracle.instantiate(desc, 160, 90)
+        rt.setDOF(0.35, 14.0)
+        rt.render()
+        dof = rt.ctx.read_accum()
+        rt.toggleAccumulation(False)
+        rt.render()
+        rt.render()
+        outs.append((dof, rt.ctx.read_result(), rt.ctx.read_accum(), rt.getNumAccumulationFrames()))
+        rt.close()
+    (g_dof, g_res, g_acc, g_n), (c_dof, c_res, c_acc, c_n) = outs
+    assert_1spp(g_dof, c_dof)
+    assert g_n == c_n == 0
+    assert (g_acc == 0).all() and (c_acc == 0).all()  # toggling resets, and nothing accumulates while disabled
+    assert (np.abs(g_res.astype(int) - c_res.astype(int)).max(-1) <= 1).mean() >= 0.995 and (g_res[..., 3] == 255).all()
+    # the lens really changes the image
+    rt, sc, res = scenes.instantiate(desc, 160, 90)
+    rt.render()
+    sharp = rt.ctx.read_accum()
+    rt.close()
+    assert np.abs(sharp[..., :3] - g_dof[..., :3]).mean() > 1e-3
+
+
+def test_resize_reallocates_and_resets(oracle):
+    desc = scenes.small_mesh_scene(seed=12, n_objects=3, detail=6)
+    rt, sc, res = scenes.instantiate(desc, 64, 36)
+    rt.render()
+    rt.onResize(96, 54)          # RayTracer::onResize (RayTracer.cpp:494-501)
+    assert rt.getNumAccumulationFrames() == 0 and rt.ctx.read_accum().shape == (54, 96, 4) and (rt.ctx.read_accum() == 0).all()
+    rt.render()
+    a = rt.ctx.read_accum()
+    rt.close()
+    ort, _, _ = oracle.instantiate(desc, 96, 54)
+    ort.render()
+    assert_1spp(a, ort.ctx.read_accum())
+    ort.close()
