@@ -381,6 +381,174 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
     }
 }
 
+// ---- packet traversal of camera rays --------------------------------------------------------------------------------
+// Camera rays arrive one 8x8 pixel tile per 64 consecutive positions, i.e. one tile per wave, and the rays of a tile
+// walk almost the same nodes. So the wave traverses the tree ONCE for all its lanes: the current node is wave-uniform,
+// its 64 bytes come through the scalar cache into SGPRs (s_load, no vector-memory gather at all), every lane tests its
+// own ray against the four child boxes, a child is visited when ANY lane enters it (`__ballot`), order = entry
+// distance of the first lane that enters, one shared stack of node references in LDS, no divergent control flow.
+// Each lane keeps its own closest hit with the same arithmetic as the per-ray kernel, so results agree bit for bit
+// (ties aside). Used for segment 0 only; bounce rays are incoherent and stay on the per-ray kernel.
+constexpr int kPacketStack = 128;  // shared entries per wave (>= 3 * tree depth + 4, checked on the host)
+
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* __restrict__ nodes, const float4* __restrict__ tris,
+                                                                  SceneView s, okrt_render_data rd, TileView tile, RayQueue q, HitBuffer hb,
+                                                                  ShardView sv, uint32_t cameraFrames, unsigned long long* counters,
+                                                                  unsigned long long* rayTotals) {
+    __shared__ uint32_t sShared[kTraceThreads / 64][kPacketStack];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* stack = sShared[wave];
+    if (!COUNT && blockIdx.x == 0 && tid == 0) {
+        const unsigned long long n = (unsigned long long)tile.W * tile.rows * cameraFrames;
+        atomicAdd(&rayTotals[0], n);
+        atomicAdd(&rayTotals[1], n);
+    }
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t shard = sv.xcdAffinity ? (xcc & (kShards - 1)) : 0u, tried = 0;
+    uint32_t nNodes = 0, nTris = 0, nSeg = 0;
+
+    for (;;) {
+        // ---- next tile: 64 positions from this XCD's shard, stealing when it is dry (all wave-uniform) -----------
+        uint32_t base = kInvalid;
+        while (tried < kShards) {
+            const uint32_t cnt = sv.count(shard);
+            uint32_t bpos = 0;
+            if (lane == 0) bpos = atomicAdd(&sv.cursors[shard * kCursorStride], 64u);
+            bpos = __builtin_amdgcn_readfirstlane(bpos);
+            if (bpos < cnt) {
+                base = shard * sv.cap + bpos;
+                tried = 0;
+                break;
+            }
+            uint32_t seen = 0xFFFFFFFFu, lim = 0;
+            if (lane < kShards) {
+                seen = __hip_atomic_load(&sv.cursors[lane * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lim = sv.count(lane);
+            }
+            const uint32_t live = (uint32_t)__ballot(seen < lim) & ((1u << kShards) - 1u);
+            if (!live) {
+                tried = kShards;
+                break;
+            }
+            const uint32_t rot = ((live >> shard) | (live << (kShards - shard))) & ((1u << kShards) - 1u);
+            shard = (shard + (uint32_t)__builtin_ctz(rot)) & (kShards - 1);
+            tried++;
+        }
+        if (base == kInvalid) break;
+
+        const uint32_t mine = base + lane;
+        const float4 A = q.a[mine], B = q.b[mine];
+        Ray ray;
+        ray.origin = mk(A.x, A.y, A.z);
+        ray.direction = mk(A.w, B.x, B.y);
+        const bool valid = __float_as_uint(B.w) != kInvalid;
+        if (__ballot(valid) == 0ull) continue;
+        if (valid) nSeg++;
+        const V3 ro = ray.origin;
+        const V3 rdir = valid ? normalize(ray.direction) : mk(0.f, 0.f, 1.f);  // the shader re-normalises per instance (:276)
+        V3 iq = rcp3(rdir);
+        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
+        float best = valid ? kFltMax : -1.f;  // an invalid lane can never enter a box (tnear < best fails)
+        float hbu = 0.f, hbv = 0.f;
+        uint32_t hitIdx = kInvalid, hitTri = kInvalid;
+        if (valid)
+            for (uint32_t i = 0; i < rd.numSpheres; i++) {  // RaytracerCS.hlsl:232-242 (original direction)
+                float d = rayAndSphere(ray, ld3(s.spheres[i].position), s.spheres[i].radius);
+                if (d > 0.f && d < best) {
+                    best = d;
+                    hitIdx = i;
+                }
+            }
+
+        uint32_t sp = 0, cur = 0;  // wave-uniform
+        for (;;) {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            if (!(cur & kLeafBit)) {
+                const uint4* np = nodes + (size_t)cur * 4;  // uniform address: scalar loads
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                if (COUNT) nNodes++;
+                const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
+                const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
+                const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
+                const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
+                const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
+                const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
+                const uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
+                uint32_t key[4], ref[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
+                                              fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
+                    const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
+                                             fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
+                    const bool hit = tfar >= tnear && tfar > 0.f && tnear < best;
+                    const unsigned long long m = ch[k] != kEmptyRef ? __ballot(hit) : 0ull;
+                    // order key: entry distance (clamped to >= 0, so its bits sort as an integer) of the first lane entering
+                    const float t0 = __shfl(fmaxf(tnear, 0.f), m ? __ffsll((long long)m) - 1 : 0, 64);
+                    key[k] = m ? __float_as_uint(t0) : 0xFFFFFFFFu;
+                    ref[k] = ch[k];
+                }
+#define OKRT_USWAP(i, j)                                         \
+    if (key[j] < key[i]) {                                       \
+        const uint32_t tk_ = key[i]; key[i] = key[j]; key[j] = tk_; \
+        const uint32_t tr_ = ref[i]; ref[i] = ref[j]; ref[j] = tr_; \
+    }
+                OKRT_USWAP(0, 1) OKRT_USWAP(2, 3) OKRT_USWAP(0, 2) OKRT_USWAP(1, 3) OKRT_USWAP(1, 2)
+#undef OKRT_USWAP
+                // push the far ones (3, 2, 1), continue with the nearest; everything here is wave-uniform
+#pragma unroll
+                for (int k = 3; k >= 1; --k)
+                    if (key[k] != 0xFFFFFFFFu && sp < (uint32_t)kPacketStack) {
+                        if (lane == 0) stack[sp] = ref[k];
+                        sp++;
+                    }
+                if (key[0] != 0xFFFFFFFFu) {
+                    cur = ref[0];
+                    continue;
+                }
+            } else {
+                const uint32_t count = ((cur >> 27) & 15u) + 1u;
+                const float4* tp = tris + (size_t)(cur & 0x07FFFFFFu) * 3;  // uniform address: scalar loads
+                for (uint32_t j = 0; j < count; ++j, tp += 3) {
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    if (COUNT) nTris++;
+                    float bu = 0.f, bv = 0.f;
+                    const float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
+                    if (t > 0.f) {
+                        const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314
+                        if (d < best) {
+                            best = d;
+                            hbu = bu;
+                            hbv = bv;
+                            hitTri = __float_as_uint(t0.w);
+                            hitIdx = __float_as_uint(t1.w);
+                        }
+                    }
+                }
+            }
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp];  // same address in every lane (broadcast); written by lane 0 above
+        }
+        if (valid) {
+            hb.h[mine] = make_float4(best, hbu, hbv, __uint_as_float(hitIdx));
+            hb.tri[mine] = hitTri;
+        }
+    }
+    if (COUNT && counters) {
+        uint32_t v = nSeg;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) {
+            if (v) atomicAdd(&counters[1], (unsigned long long)v);
+            // wave-uniform visit counts: every lane of the wave saw the same nodes / triangles
+            atomicAdd(&counters[10], (unsigned long long)nNodes * 64ull);
+            atomicAdd(&counters[11], (unsigned long long)nTris * 64ull);
+        }
+    }
+}
+
 // Shading of one path segment. FIRST: items are pixels (tile order), the camera ray is regenerated.
 // Finished paths (miss, or last segment) accumulate; the rest are compacted into `qOut`.
 template <bool FIRST, bool COUNT>
@@ -614,7 +782,15 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     mark();
     // segment 0: camera rays into q[0] (a, b only), then the same trace kernel as every other segment
     hipLaunchKernelGGL(generateKernel, sg, dim3(256), 0, stream, rd, t, fs.q[0], perFrame, frames);
-    if (cnt)
+    static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
+    const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
+    static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
+    const dim3 pg((unsigned)(fs.traceBlocks / 6 * envPacketBlocks));  // (29 VGPRs, 2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
+    if (packet && cnt)
+        hipLaunchKernelGGL((tracePacketKernel<true>), pg, tb, 0, stream, fs.nodes, fs.tris, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+    else if (packet)
+        hipLaunchKernelGGL((tracePacketKernel<false>), pg, tb, 0, stream, fs.nodes, fs.tris, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+    else if (cnt)
         hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
     else
         hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
