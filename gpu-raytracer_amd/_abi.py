@@ -19,7 +19,8 @@ TABLE_OCT, TABLE_SPHERE, TABLE_MESH = 5, 6, 7
 TABLE_DIR_LIGHT, TABLE_POINT_LIGHT, TABLE_SPOT_LIGHT = 8, 9, 10
 TABLE_STRIDE = {0: 36, 1: 132, 2: 36, 5: 48, 6: 84, 7: 232, 8: 32, 9: 32, 10: 48}
 
-OPT_TRAVERSAL, OPT_MAX_BOUNCES, OPT_COUNTERS, OPT_TIMING = 0, 1, 2, 3
+OPT_TRAVERSAL, OPT_MAX_BOUNCES, OPT_COUNTERS, OPT_TIMING, OPT_BUILDER = 0, 1, 2, 3, 4
+BUILDER_HOST, BUILDER_DEVICE = 0, 1
 TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
 
 
@@ -88,6 +89,9 @@ PRODUCT_ONLY = {
     "get_stage_ms": (C.c_int, [P, C.POINTER(C.c_float * 3), C.POINTER(U32)]),
     "write_accum_f32x4": (C.c_int, [P, P]),
     "get_api": (P, []),
+    "commit": (C.c_int, [P]),
+    "get_build_info": (C.c_int, [P, P]),
+    "get_fast_structure": (C.c_int, [P, P, U32, P, U32]),
 }
 HEADER_SYMBOLS = ["okrt_" + n for n in list(SIGNATURES) + list(PRODUCT_ONLY)]
 

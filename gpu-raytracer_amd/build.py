@@ -29,12 +29,25 @@ def _run(cmd, cwd=None):
 
 
 def build_device(force=False):
+    """One object per source (cached under _build/, compiled in parallel), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.cpp")))
-    deps = src + glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(REPO, "include", "okrt.h")]
+    headers = glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(REPO, "include", "okrt.h")]
     out = os.path.join(PKG, "libokrt.so")
-    if force or _newer(out, deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIP_FLAGS + ["-o", out] + src)
+    objdir = os.path.join(PKG, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = [f for f in HIP_FLAGS if f != "-shared"]
+    jobs = []
+    for f in src:
+        obj = os.path.join(objdir, os.path.basename(f) + ".o")
+        if force or _newer(obj, [f] + headers):
+            jobs.append([hipcc] + flags + ["-c", f, "-o", obj])
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(_run, jobs))
+    objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in src]
+    if force or jobs or _newer(out, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 

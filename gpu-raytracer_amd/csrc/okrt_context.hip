@@ -49,6 +49,8 @@ struct okrt_ctx {
     bool tablesValid = false;
     FastScene* fast = nullptr;  // derived structure (okrt_fast.h); rebuilt when geometry changes
     bool fastDirty = true;
+    bool fastGeometryDirty = true;  // t0 / t2 changed since the last build (device builder's leaf-range cache)
+    uint32_t builder = 0;           // OKRT_OPT_BUILDER
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
     // OKRT_OPT_TIMING: ring of per-render event lists (kernel boundaries, in launch order)
     struct TimedFrame { std::vector<hipEvent_t> ev; int used = 0; bool fast = false; uint32_t frames = 1; };
@@ -275,6 +277,7 @@ okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint3
     if (slot == OKRT_TABLE_TRI_POS || slot == OKRT_TABLE_TRI_INFO || slot == OKRT_TABLE_BVH || slot == OKRT_TABLE_OCT || slot == OKRT_TABLE_MESH) {
         c->tablesDirty = true;
         c->fastDirty = true;
+        if (slot == OKRT_TABLE_TRI_POS || slot == OKRT_TABLE_BVH) c->fastGeometryDirty = true;
     }
     return OKRT_OK;
 }
@@ -398,6 +401,69 @@ okrt_status okrt_render_frames(okrt_ctx* c, const okrt_render_data* rd, uint32_t
     return OKRT_OK;
 }
 
+static okrt_status ensureTables(okrt_ctx* c) {
+    if (c->tablesDirty) {
+        okrt_status s = validateTables(c);
+        c->tablesValid = s == OKRT_OK;
+        c->tablesDirty = false;
+        if (s != OKRT_OK) return s;
+    }
+    if (!c->tablesValid) return fail(c, OKRT_ERR_RANGE, "render: the uploaded tables failed validation");
+    return OKRT_OK;
+}
+
+// (Re)derives the traversal structure when a geometry / instance / octree table changed since the last build.
+static okrt_status ensureFast(okrt_ctx* c) {
+    if (!c->fastDirty) return OKRT_OK;
+    std::string msg;
+    FastInputs in;
+    in.triPos = (const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].host.data();
+    in.numTris = c->tables[OKRT_TABLE_TRI_POS].count;
+    in.bvh = (const BvhNodeRec*)c->tables[OKRT_TABLE_BVH].host.data();
+    in.numNodes = c->tables[OKRT_TABLE_BVH].count;
+    in.oct = (const OctNodeRec*)c->tables[OKRT_TABLE_OCT].host.data();
+    in.numOct = c->tables[OKRT_TABLE_OCT].count;
+    in.meshes = (const MeshRec*)c->tables[OKRT_TABLE_MESH].host.data();
+    in.numMeshes = c->tables[OKRT_TABLE_MESH].count;
+    in.geometryChanged = c->fastGeometryDirty;
+    FastDeviceTables dev{(const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].dev.ptr, (const MeshRec*)c->tables[OKRT_TABLE_MESH].dev.ptr};
+    OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    if (!fastBuild(&c->fast, in, dev, c->builder, c->stream, msg)) return fail(c, OKRT_ERR_DEVICE, "fast structure: " + msg);
+    c->fastDirty = false;
+    c->fastGeometryDirty = false;
+    return OKRT_OK;
+}
+
+okrt_status okrt_commit(okrt_ctx* c) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    okrt_status s = ensureTables(c);
+    if (s != OKRT_OK) return s;
+    return ensureFast(c);
+}
+
+okrt_status okrt_get_build_info(okrt_ctx* c, okrt_build_info* out) {
+    if (!c || !out) return OKRT_ERR_INVALID_ARG;
+    FastBuildInfo bi;
+    fastBuildInfo(c->fast, &bi);
+    out->builder = bi.builder;
+    out->num_nodes = bi.numNodes;
+    out->num_triangles = bi.numTris;
+    out->max_depth = bi.maxDepth;
+    out->device_ms = bi.deviceMs;
+    out->wall_ms = bi.wallMs;
+    return OKRT_OK;
+}
+
+okrt_status okrt_get_fast_structure(okrt_ctx* c, void* nodes64, uint32_t node_capacity, void* tris48, uint32_t tri_capacity) {
+    if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    std::string msg;
+    if (c->fastDirty || !fastReadStructure(c->fast, nodes64, node_capacity, tris48, tri_capacity, c->stream, msg))
+        return fail(c, c->fastDirty ? OKRT_ERR_STATE : OKRT_ERR_INVALID_ARG, c->fastDirty ? "structure not built (okrt_commit)" : msg);
+    return OKRT_OK;
+}
+
 static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
     if (!c->W) return fail(c, OKRT_ERR_STATE, "render before resize");
@@ -406,13 +472,8 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
         rd->numPointLights > c->tables[OKRT_TABLE_POINT_LIGHT].count || rd->numSpotLights > c->tables[OKRT_TABLE_SPOT_LIGHT].count)
         return fail(c, OKRT_ERR_RANGE, "render: a count in RenderData exceeds its uploaded table");
     OKRT_HIP(c, hipSetDevice(c->device));
-    if (c->tablesDirty) {
-        okrt_status s = validateTables(c);
-        c->tablesValid = s == OKRT_OK;
-        c->tablesDirty = false;
-        if (s != OKRT_OK) return s;
-    }
-    if (!c->tablesValid) return fail(c, OKRT_ERR_RANGE, "render: the uploaded tables failed validation");
+    okrt_status vs = ensureTables(c);
+    if (vs != OKRT_OK) return vs;
     if (!c->tile.rows) return OKRT_OK;
 
     SceneView view = makeView(c);
@@ -442,21 +503,8 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
             tf->fast = false;
         }
     } else {
-        if (c->fastDirty) {
-            std::string msg;
-            FastInputs in;
-            in.triPos = (const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].host.data();
-            in.numTris = c->tables[OKRT_TABLE_TRI_POS].count;
-            in.bvh = (const BvhNodeRec*)c->tables[OKRT_TABLE_BVH].host.data();
-            in.numNodes = c->tables[OKRT_TABLE_BVH].count;
-            in.oct = (const OctNodeRec*)c->tables[OKRT_TABLE_OCT].host.data();
-            in.numOct = c->tables[OKRT_TABLE_OCT].count;
-            in.meshes = (const MeshRec*)c->tables[OKRT_TABLE_MESH].host.data();
-            in.numMeshes = c->tables[OKRT_TABLE_MESH].count;
-            OKRT_HIP(c, hipStreamSynchronize(c->stream));
-            if (!fastBuild(&c->fast, in, c->stream, msg)) return fail(c, OKRT_ERR_DEVICE, "fast structure: " + msg);
-            c->fastDirty = false;
-        }
+        okrt_status fs = ensureFast(c);
+        if (fs != OKRT_OK) return fs;
         std::string msg;
         if (!launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, (unsigned long long*)c->counters.ptr, c->stream,
                         tf ? tf->ev.data() : nullptr, frames, msg))
@@ -517,6 +565,14 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             c->maxBounces = (int)value;
             return OKRT_OK;
         case OKRT_OPT_COUNTERS: c->countersOn = value != 0; return OKRT_OK;
+        case OKRT_OPT_BUILDER:
+            if (value != 0 && value != 1) return fail(c, OKRT_ERR_INVALID_ARG, "builder: 0 (host SAH) or 1 (device PLOC)");
+            if ((uint32_t)value != c->builder) {
+                c->builder = (uint32_t)value;
+                c->fastDirty = true;
+                c->fastGeometryDirty = true;
+            }
+            return OKRT_OK;
         case OKRT_OPT_TIMING: {
             if (value < 0 || value > 4096) return fail(c, OKRT_ERR_INVALID_ARG, "timing: ring size 0..4096");
             OKRT_HIP(c, hipSetDevice(c->device));

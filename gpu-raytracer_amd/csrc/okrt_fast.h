@@ -53,6 +53,7 @@ struct FastInputs {  // host copies of the uploaded reference tables
     const BvhNodeRec* bvh; uint32_t numNodes;
     const OctNodeRec* oct; uint32_t numOct;
     const MeshRec* meshes; uint32_t numMeshes;
+    bool geometryChanged = true;  // t0 / t2 were re-uploaded since the last build (else only instances / octree moved)
 };
 
 // Host-side result of the build (okrt_fast_build.cpp); uploaded by fastBuild.
@@ -64,9 +65,53 @@ struct FastHostScene {
 };
 void buildFastHost(const FastInputs& in, FastHostScene& out);
 
+// Grow-only device allocation.
+template <class T>
+struct DeviceArray {
+    T* p = nullptr;
+    size_t cap = 0;
+    bool need(size_t n, std::string& err, bool headroom = false) {
+        if (n <= cap) return true;
+        release();
+        if (headroom) n += n / 8;
+        hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            err = std::string("hipMalloc: ") + hipGetErrorString(e);
+            return false;
+        }
+        cap = n;
+        return true;
+    }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Device-side build (okrt_fast_build_device.hip): the same structure, made on the GPU from the tables in HBM.
+struct FastDeviceTables { const TriangleRec* triPos; const MeshRec* meshes; };
+struct FastDeviceResult {
+    DeviceArray<uint4>& nodes;   // 4 x uint4 per Node4Q
+    DeviceArray<float4>& tris;   // 3 x float4 per Tri48
+    uint32_t numNodes = 0, numTris = 0, maxDepth = 0;
+    bool allIdentity = true;
+    float buildMs = 0.f;         // device timeline, first kernel to last
+};
+struct DeviceBuilder;
+DeviceBuilder* deviceBuilderCreate();
+void deviceBuilderDestroy(DeviceBuilder*);
+bool buildFastDevice(DeviceBuilder& b, const FastInputs& in, const FastDeviceTables& dev, hipStream_t stream, FastDeviceResult& out, std::string& err);
+
 struct FastScene;  // device-resident structure + the wavefront queues
 
-bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std::string& err);
+struct FastBuildInfo { uint32_t builder, numNodes, numTris, maxDepth; float deviceMs, wallMs; };
+// builder: 0 = host binned SAH (okrt_fast_build.cpp), 1 = device PLOC (okrt_fast_build_device.hip)
+bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& dev, uint32_t builder, hipStream_t stream, std::string& err);
+void fastBuildInfo(const FastScene* scene, FastBuildInfo* info);
+// copies the structure back to the host (tests); either pointer may be null
+bool fastReadStructure(const FastScene* scene, void* nodes, uint32_t nodeCapacity, void* tris, uint32_t triCapacity, hipStream_t stream, std::string& err);
 void fastDestroy(FastScene* scene);
 // One frame through the wavefront pipeline. Returns false (with err) if queue memory cannot be had.
 // `counters` (optional) = full okrt_counters accounting; `rayTotals` (always) = the same buffer, of which

@@ -27,7 +27,9 @@
 //     shader's edge convention, hit distance = length(dir*t) (RaytracerCS.hlsl:276,285,306-316),
 //     so for identity instances (all benchmark scenes) the closest hit equals the reference's bit
 //     for bit; only equal-distance ties may resolve to a different triangle.
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 
 #include "okrt_fast.h"
 
@@ -671,10 +673,12 @@ constexpr uint32_t kCursorBase = kMaxSegments * kShards * kCursorStride;
 constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorStride;
 
 struct FastScene {
-    uint4* nodes = nullptr;
-    float4* tris = nullptr;
+    DeviceArray<uint4> nodes;   // 4 x uint4 per Node4Q
+    DeviceArray<float4> tris;   // 3 x float4 per Tri48
     uint32_t numNodes = 0, numTris = 0, maxDepth = 0;
     bool allIdentity = true;
+    DeviceBuilder* builder = nullptr;  // device-side build scratch (okrt_fast_build_device.hip), made on first use
+    FastBuildInfo info = {};
     // pipeline state, sized lazily for the tile
     size_t capacity = 0;
     RayQueue q[2] = {};
@@ -688,25 +692,40 @@ struct FastScene {
     size_t radianceCap = 0;
 };
 
-bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std::string& err) {
+bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& tables, uint32_t builder, hipStream_t stream, std::string& err) {
     if (!*scene) *scene = new FastScene();
     FastScene& fs = **scene;
-    FastHostScene host;
-    buildFastHost(in, host);
-    fs.numNodes = (uint32_t)host.nodes.size();
-    fs.numTris = (uint32_t)host.tris.size();
-    fs.maxDepth = host.maxDepth;
-    fs.allIdentity = host.allIdentity;
-    if (!devAlloc(&fs.nodes, host.nodes.size() * 4, err)) return false;
-    if (!devAlloc(&fs.tris, std::max<size_t>(host.tris.size(), 1) * 3, err)) return false;
-    hipError_t e = hipMemcpyAsync(fs.nodes, host.nodes.data(), host.nodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess && !host.tris.empty())
-        e = hipMemcpyAsync(fs.tris, host.tris.data(), host.tris.size() * sizeof(Tri48), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `host` dies at return
-    if (e != hipSuccess) {
-        err = std::string("upload: ") + hipGetErrorString(e);
-        return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    float deviceMs = 0.f;
+    if (builder == 1u) {
+        if (!fs.builder) fs.builder = deviceBuilderCreate();
+        FastDeviceResult r{fs.nodes, fs.tris};
+        if (!buildFastDevice(*fs.builder, in, tables, stream, r, err)) return false;
+        fs.numNodes = r.numNodes;
+        fs.numTris = r.numTris;
+        fs.maxDepth = r.maxDepth;
+        fs.allIdentity = r.allIdentity;
+        deviceMs = r.buildMs;
+    } else {
+        FastHostScene host;
+        buildFastHost(in, host);
+        fs.numNodes = (uint32_t)host.nodes.size();
+        fs.numTris = (uint32_t)host.tris.size();
+        fs.maxDepth = host.maxDepth;
+        fs.allIdentity = host.allIdentity;
+        if (!fs.nodes.need(host.nodes.size() * 4, err)) return false;
+        if (!fs.tris.need(std::max<size_t>(host.tris.size(), 1) * 3, err)) return false;
+        hipError_t e = hipMemcpyAsync(fs.nodes.p, host.nodes.data(), host.nodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && !host.tris.empty())
+            e = hipMemcpyAsync(fs.tris.p, host.tris.data(), host.tris.size() * sizeof(Tri48), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `host` dies at return
+        if (e != hipSuccess) {
+            err = std::string("upload: ") + hipGetErrorString(e);
+            return false;
+        }
     }
+    fs.info = {builder, fs.numNodes, fs.numTris, fs.maxDepth, deviceMs,
+               std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()};
     // spill slab: a visit pushes at most 3 entries, so 3*depth bounds the stack
     int dev = 0, cus = 256;
     hipGetDevice(&dev);
@@ -722,9 +741,37 @@ bool fastBuild(FastScene** scene, const FastInputs& in, hipStream_t stream, std:
     return true;
 }
 
+void fastBuildInfo(const FastScene* fs, FastBuildInfo* info) {
+    if (fs) *info = fs->info;
+    else std::memset(info, 0, sizeof(*info));
+}
+
+bool fastReadStructure(const FastScene* fs, void* nodes, uint32_t nodeCapacity, void* tris, uint32_t triCapacity, hipStream_t stream, std::string& err) {
+    if (!fs) {
+        err = "no structure built yet";
+        return false;
+    }
+    if ((nodes && nodeCapacity < fs->numNodes) || (tris && triCapacity < fs->numTris)) {
+        err = "capacity too small";
+        return false;
+    }
+    hipError_t e = hipSuccess;
+    if (nodes && fs->numNodes) e = hipMemcpyAsync(nodes, fs->nodes.p, (size_t)fs->numNodes * sizeof(Node4Q), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && tris && fs->numTris) e = hipMemcpyAsync(tris, fs->tris.p, (size_t)fs->numTris * sizeof(Tri48), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        err = std::string("read structure: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
 void fastDestroy(FastScene* fs) {
     if (!fs) return;
-    for (void* p : {(void*)fs->nodes, (void*)fs->tris, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
+    fs->nodes.release();
+    fs->tris.release();
+    if (fs->builder) deviceBuilderDestroy(fs->builder);
+    for (void* p : {(void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
         if (p) hipFree(p);
     for (RayQueue& q : fs->q)
         for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
@@ -766,7 +813,7 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
         return false;
     }
     hipMemsetAsync(fs.counts, 0, (size_t)kCountWords * sizeof(uint32_t), stream);
-    FastView fv{fs.nodes, fs.tris, fs.overflow, fs.overflowCap};
+    FastView fv{fs.nodes.p, fs.tris.p, fs.overflow, fs.overflowCap};
     const dim3 tb(kTraceThreads), tg(fs.traceBlocks);
     const dim3 sg((unsigned)(items / 256));
     const bool cnt = counters != nullptr;
@@ -787,9 +834,9 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
     const dim3 pg((unsigned)(fs.traceBlocks / 6 * envPacketBlocks));  // (29 VGPRs, 2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
     if (packet && cnt)
-        hipLaunchKernelGGL((tracePacketKernel<true>), pg, tb, 0, stream, fs.nodes, fs.tris, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+        hipLaunchKernelGGL((tracePacketKernel<true>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
     else if (packet)
-        hipLaunchKernelGGL((tracePacketKernel<false>), pg, tb, 0, stream, fs.nodes, fs.tris, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+        hipLaunchKernelGGL((tracePacketKernel<false>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
     else if (cnt)
         hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
     else

@@ -164,6 +164,27 @@ class Context:
     def set_stream(self, stream_ptr):
         self._ck(self.fns.set_stream(self.h, stream_ptr), "set_stream")
 
+    def commit(self):
+        """Validate the tables and (re)build the traversal structure now (okrt_commit)."""
+        self._ck(self.fns.commit(self.h), "commit")
+
+    def build_info(self):
+        class _Info(C.Structure):
+            _fields_ = [("builder", U32), ("num_nodes", U32), ("num_triangles", U32), ("max_depth", U32),
+                        ("device_ms", C.c_float), ("wall_ms", C.c_float)]
+        bi = _Info()
+        self._ck(self.fns.get_build_info(self.h, C.byref(bi)), "get_build_info")
+        return {k: getattr(bi, k) for k, _ in _Info._fields_}
+
+    def fast_structure(self):
+        """(nodes uint32 [n,16], tris uint32 [m,12]) — the derived structure, layouts of csrc/okrt_fast.h."""
+        bi = self.build_info()
+        nodes = np.zeros((max(bi["num_nodes"], 1), 16), np.uint32)
+        tris = np.zeros((max(bi["num_triangles"], 1), 12), np.uint32)
+        self._ck(self.fns.get_fast_structure(self.h, nodes.ctypes.data_as(P), nodes.shape[0], tris.ctypes.data_as(P), tris.shape[0]),
+                 "get_fast_structure")
+        return nodes[:bi["num_nodes"]], tris[:bi["num_triangles"]]
+
 
 # ---- C++ host layer -----------------------------------------------------------------------------
 class Material(C.Structure):
@@ -290,6 +311,10 @@ class Scene:
         e = self.lib.okh_scene_create_entity(self.h)
         self.lib.okh_scene_set_transform(self.h, e, _f3(position), _f3(rotation), _f3(scale))
         return e
+
+    def set_transform(self, e, position=(0, 0, 0), rotation=(0, 0, 0), scale=(1, 1, 1)):
+        """Move an entity (the reference's ImGui transform edit, Application.cpp:287-317); follow with createOctTree."""
+        self.lib.okh_scene_set_transform(self.h, e, _f3(position), _f3(rotation), _f3(scale))
 
     def add_mesh(self, e, mesh_id, material=None):
         m = material or Material()

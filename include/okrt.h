@@ -123,8 +123,18 @@ typedef enum okrt_option {
     OKRT_OPT_COUNTERS = 2,
     /* n > 0 = record HIP events around every kernel of each render (ring of the last n renders) so
      * okrt_last_render_ms / okrt_get_stage_ms work; 0 = off (default). */
-    OKRT_OPT_TIMING = 3
+    OKRT_OPT_TIMING = 3,
+    /* Who derives the traversal structure when a geometry / instance / octree table changed:
+     * 0 = (default) the host (binned SAH over the baked instances, then uploaded);
+     * 1 = the GPU, straight from the tables in HBM (Morton sort + parallel locally-ordered clustering + collapse to
+     *     4-wide nodes): the step the reference spends in BvhBuilder.cpp:72-97 / the octree rebuild of
+     *     Application.cpp:312-317 on every scene edit, at interactive rates. Both cover exactly the triangles the
+     *     reference shader reaches, so renders agree up to equal-distance ties. */
+    OKRT_OPT_BUILDER = 4
 } okrt_option;
+
+#define OKRT_BUILDER_HOST 0
+#define OKRT_BUILDER_DEVICE 1
 
 #define OKRT_TRAVERSAL_REFERENCE 0
 #define OKRT_TRAVERSAL_FAST 1
@@ -224,6 +234,23 @@ okrt_status okrt_last_render_ms(okrt_ctx* ctx, float* out_ms);
  * megakernel), out_ms[1] = shading kernels, out_ms[2] = everything else inside the frame (memsets,
  * gaps). *out_frames = number of renders summed. Synchronises. */
 okrt_status okrt_get_stage_ms(okrt_ctx* ctx, float out_ms[3], uint32_t* out_frames);
+
+/* Validates the uploaded tables and (re)builds the derived traversal structure now instead of inside the next
+ * okrt_render — the reference's "Rebuild BVH / refresh octree" moment (Application.cpp:312-317,598-604). Optional:
+ * okrt_render commits whatever is pending. */
+okrt_status okrt_commit(okrt_ctx* ctx);
+typedef struct okrt_build_info {
+    uint32_t builder;        /* OKRT_BUILDER_* that made the current structure */
+    uint32_t num_nodes;      /* 64-byte 4-wide nodes */
+    uint32_t num_triangles;  /* 48-byte baked triangles (instances x mesh triangles) */
+    uint32_t max_depth;      /* node levels + 1 */
+    float device_ms;         /* device builder: first to last kernel on the stream; 0 for the host builder */
+    float wall_ms;           /* host wall clock of the whole build incl. upload / read-backs */
+} okrt_build_info;
+okrt_status okrt_get_build_info(okrt_ctx* ctx, okrt_build_info* out);
+/* Test / tooling access: copies the derived structure to the host (64 B per node, 48 B per triangle; layouts in
+ * gpu-raytracer_amd/csrc/okrt_fast.h). Either pointer may be NULL. OKRT_ERR_STATE if nothing is built. */
+okrt_status okrt_get_fast_structure(okrt_ctx* ctx, void* nodes64, uint32_t node_capacity, void* tris48, uint32_t tri_capacity);
 
 /* ---- entry-point table -------------------------------------------------------------------------
  * The same entry points as a struct of function pointers, so a host written against this ABI
