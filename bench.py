@@ -70,6 +70,10 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
         dt = time.perf_counter() - t0
         return rt.ctx.counters()["segments"], dt, rt.ctx.tile_rows()
 
+    # one thread first ("report 1-thread and all-thread"): ~8 rows spread over the frame
+    oracle.lib.okrt_oracle_set_threads(rt.ctx.h, 1)
+    rays1, dt1, rows1 = run(max(height // 8, 1))
+    oracle.lib.okrt_oracle_set_threads(rt.ctx.h, 0)  # 0 = hardware_concurrency
     rays, dt, rows = run(max(height // 16, 1))  # calibration: ~16 rows
     rate = rays / max(dt, 1e-6)
     full_rays = rays * (height / max(rows, 1))
@@ -92,7 +96,9 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
         what = f"{frames} whole {width}x{height} frames"
     rt.close()
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (scalar C++ restatement, reference traversal order): {what}, {rays} rays in {dt:.1f} s on {cores} threads"}
+            "value_1thread": round(rays1 / dt1 / 1e6, 5),
+            "sample": f"oracle (scalar C++ restatement, reference traversal order): {what}, {rays} rays in {dt:.1f} s on {cores} threads; "
+                      f"1 thread: {rows1} rows, {rays1} rays in {dt1:.1f} s"}
 
 
 def main():

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <thread>
@@ -63,7 +64,7 @@ struct Node2 {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafSize = 4;
+static const uint32_t kLeafSize = getenv("OKRT_BUILD_LEAF") ? (uint32_t)atoi(getenv("OKRT_BUILD_LEAF")) : 4u;  // developer knob
 
 struct Builder {
     std::vector<Prim>& prims;
