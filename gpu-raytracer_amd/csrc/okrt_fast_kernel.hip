@@ -38,7 +38,13 @@ namespace okrt {
 namespace {
 
 constexpr int kTraceThreads = 256;
-constexpr int kLdsStack = 12;        // entries per lane kept in LDS
+#ifndef OKRT_LDS_STACK
+#define OKRT_LDS_STACK 10
+#endif
+#ifndef OKRT_TRACE_WAVES
+#define OKRT_TRACE_WAVES 7
+#endif
+constexpr int kLdsStack = OKRT_LDS_STACK;  // entries per lane kept in LDS
 constexpr int kRefillBelow = 40;     // refill idle lanes when fewer than this many lanes are active
 constexpr uint32_t kDone = kEmptyRef;
 constexpr uint32_t kShards = 8;      // queue shards = XCDs
@@ -50,6 +56,7 @@ constexpr uint32_t kCursorStride = 32;  // words: one cursor per 128-byte line (
 struct ShardView {
     uint32_t cap, total;
     uint32_t batch, xcdAffinity, refillBelow;  // tunables (developer knobs: OKRT_FAST_BATCH / _AFFINITY / _REFILL)
+    uint32_t nodeMin, triMin;                  // a step block runs when at least this many lanes want it (OKRT_FAST_NODE_MIN / _TRI_MIN)
     const uint32_t* counts;  // counts[s * kCursorStride]; nullptr for camera rays
     uint32_t* cursors;       // cursors[s * kCursorStride]
     __device__ uint32_t count(uint32_t s) const {
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileV
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
+__global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
                                                             HitBuffer hb, ShardView sv, uint32_t cameraFrames,
                                                             unsigned long long* counters, unsigned long long* rayTotals) {
     // (ref, entry distance) pairs, [entry][thread]; row kLdsStack is a dummy target for predicated-off pushes
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
 
     uint32_t rayIdx = kInvalid;   // the ray this lane is tracing
     uint32_t cur = kDone;         // node/leaf reference being processed, kDone = nothing
-    uint32_t post = kDone;        // a leaf found earlier and postponed (speculative traversal), kDone = none
+    uint32_t triJ = 0;            // cur is a leaf: the triangle to test next
     uint32_t sp = 0;
     V3 ro = mk(0, 0, 0), rdir = mk(0, 0, 0), iq = mk(0, 0, 0);
     float best = kFltMax, hbu = 0.f, hbv = 0.f;
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
 
 #ifdef OKRT_STAMPS
     unsigned long long tRefill = 0, tInner = 0, tLeaf = 0, tStart = __builtin_amdgcn_s_memtime(), nRefill = 0, nIter = 0, laneIters = 0;
+    unsigned long long nodeWave = 0, nodeLane = 0, leafWave = 0, leafLane = 0;  // wave-iterations and active lane-iterations of the two step blocks
 #define OKRT_T0 unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 #define OKRT_T1(acc) acc += __builtin_amdgcn_s_memtime() - t0_;
 #else
@@ -153,34 +161,6 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
         }
         return kDone;
     };
-    // Moeller-Trumbore on a leaf's triangles; the next triangle's 48 bytes are requested before the current one is tested
-    auto intersectLeaf = [&](uint32_t leaf) {
-        const uint32_t count = ((leaf >> 27) & 15u) + 1u;
-        const float4* tp = fv.tris + (size_t)(leaf & 0x07FFFFFFu) * 3;
-        float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-        for (uint32_t j = 0; j < count; ++j) {
-            float4 u0 = t0, u1 = t1, u2 = t2;
-            if (j + 1 < count) {
-                tp += 3;
-                u0 = tp[0]; u1 = tp[1]; u2 = tp[2];
-            }
-            if (COUNT) nTris++;
-            float bu = 0.f, bv = 0.f;
-            const float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
-            if (t > 0.f) {
-                const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314 with M = identity (world-space triangles)
-                if (d < best) {
-                    best = d;
-                    hbu = bu;
-                    hbv = bv;
-                    hitTri = __float_as_uint(t0.w);
-                    hitIdx = __float_as_uint(t1.w);
-                }
-            }
-            t0 = u0; t1 = u1; t2 = u2;
-        }
-    };
-
     for (;;) {
 #ifdef OKRT_STAMPS
         nIter++;
@@ -280,12 +260,37 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
             if (__ballot(rayIdx != kInvalid) == 0ull) break;  // queues drained and every lane idle
         }
 
-        // ---- inner nodes: descend nearest-first -------------------------------------------------
-        {
-        OKRT_T0
-        while (cur != kDone && !(cur & kLeafBit)) {
-            const uint4* np = fv.nodes + (size_t)cur * 4;
-            const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        // ---- one step per lane: a node visit OR a triangle test ("if-if" scheduling) ------------------------------
+        // The first version descended in a while-while loop (all node steps, then all leaf triangles); with bounce
+        // rays the lanes of a wave need very different numbers of steps before their next leaf and waited for the
+        // slowest one. Here every lane does exactly one unit of work per iteration, whichever it needs; a block is
+        // skipped when fewer than nodeMin / triMin lanes want it and the other block has work (those lanes wait one
+        // round and join a fuller block). All loads of the iteration are issued together, through one pointer per
+        // lane, before either block computes.
+        const bool isNode = cur != kDone && !(cur & kLeafBit);
+        const bool isTri = cur != kDone && (cur & kLeafBit);
+        const uint32_t wantNode = (uint32_t)__popcll(__ballot(isNode)), wantTri = (uint32_t)__popcll(__ballot(isTri));
+        bool runNode = wantNode >= sv.nodeMin, runTri = wantTri >= sv.triMin;
+        if (!runNode && !runTri) {
+            runNode = wantNode >= wantTri && wantNode;
+            runTri = !runNode && wantTri;
+        }
+        const bool stepNode = isNode && runNode, stepTri = isTri && runTri;
+        uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, d2 = d0, d3 = d0;
+        if (stepNode || stepTri) {
+            const uint4* p = stepNode ? fv.nodes + (size_t)cur * 4 : (const uint4*)fv.tris + (size_t)((cur & 0x07FFFFFFu) + triJ) * 3;
+            d0 = p[0];
+            d1 = p[1];
+            d2 = p[2];
+            if (stepNode) d3 = p[3];
+        }
+        if (stepNode) {
+            OKRT_T0
+#ifdef OKRT_STAMPS
+            nodeLane++;
+            if ((int)lane == __ffsll((long long)__ballot(true)) - 1) nodeWave++;
+#endif
+            const uint4 n0 = d0, n1 = d1, n2 = d2, n3 = d3;
             if (COUNT) nNodes++;
             float tn[4];
             uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
@@ -340,35 +345,47 @@ __global__ __launch_bounds__(kTraceThreads) void traceKernel(FastView fv, SceneV
                 }
             }
             cur = n ? ch[0] : popNext();
-            // speculative traversal: a lane that reaches a leaf parks it and keeps descending, so that it does not
-            // idle while the rest of the wave is still in this loop; both leaves are intersected below
-            if (cur != kDone && (cur & kLeafBit) && post == kDone) {
-                post = cur;
-                cur = popNext();
+            triJ = 0;
+            OKRT_T1(tInner)
+        }
+        if (stepTri) {  // Moeller-Trumbore on triangle triJ of the leaf
+            OKRT_T0
+#ifdef OKRT_STAMPS
+            leafLane++;
+            if ((int)lane == __ffsll((long long)__ballot(true)) - 1) leafWave++;
+#endif
+            if (COUNT) nTris++;
+            float bu = 0.f, bv = 0.f;
+            const float t = rayAndTriangleEdges(ro, rdir, mk(__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)),
+                                                mk(__uint_as_float(d1.x), __uint_as_float(d1.y), __uint_as_float(d1.z)),
+                                                mk(__uint_as_float(d2.x), __uint_as_float(d2.y), __uint_as_float(d2.z)), bu, bv);
+            if (t > 0.f) {
+                const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314 with M = identity (world-space triangles)
+                if (d < best) {
+                    best = d;
+                    hbu = bu;
+                    hbv = bv;
+                    hitTri = d0.w;
+                    hitIdx = d1.w;
+                }
             }
+            if (++triJ > ((cur >> 27) & 15u)) {  // count - 1 is stored
+                cur = popNext();
+                triJ = 0;
+            }
+            OKRT_T1(tLeaf)
         }
-
-        OKRT_T1(tInner)
-        }
-
-        // ---- leaf: Moeller-Trumbore on its triangles -------------------------------------------------
-        OKRT_T0
-        if (post != kDone) {
-            intersectLeaf(post);
-            post = kDone;
-        }
-        if (cur != kDone && (cur & kLeafBit)) {
-            intersectLeaf(cur);
-            cur = popNext();
-        }
-        OKRT_T1(tLeaf)
     }
 
 #ifdef OKRT_STAMPS
+    for (int off = 32; off > 0; off >>= 1) {
+        nodeWave += __shfl_down(nodeWave, off, 64); nodeLane += __shfl_down(nodeLane, off, 64);
+        leafWave += __shfl_down(leafWave, off, 64); leafLane += __shfl_down(leafLane, off, 64);
+    }
     if (COUNT && counters && lane == 0) {  // cycle sums per wave: n_oct=refill, n_mesh=inner, n_node=leaf, n_tri=total, mesh_hits=#refills, sphere_hits=#iters, tex_taps=active lane-iters
         atomicAdd(&counters[2], tRefill); atomicAdd(&counters[3], tInner); atomicAdd(&counters[4], tLeaf);
         atomicAdd(&counters[5], __builtin_amdgcn_s_memtime() - tStart);
-        atomicAdd(&counters[6], nRefill); atomicAdd(&counters[7], nIter); atomicAdd(&counters[8], laneIters);
+        atomicAdd(&counters[6], nodeWave); atomicAdd(&counters[7], nodeLane); atomicAdd(&counters[8], leafWave); atomicAdd(&counters[9], leafLane);
     }
 #endif
     if (COUNT && counters) {
@@ -687,7 +704,7 @@ struct FastScene {
                                  // (every counter on its own 128-byte line: device-scope atomics serialise per line)
     uint2* overflow = nullptr;
     uint32_t overflowCap = 0;
-    int traceBlocks = 0;
+    int traceBlocks = 0, cus = 0;
     float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
     size_t radianceCap = 0;
 };
@@ -730,7 +747,8 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
     int dev = 0, cus = 256;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : 6);
+    fs.cus = cus;
+    fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : OKRT_TRACE_WAVES);
     uint32_t need = 3 * fs.maxDepth + 4;
     uint32_t cap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;
     if (cap != fs.overflowCap || !fs.overflow) {
@@ -821,9 +839,11 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     auto mark = [&]() { if (events) hipEventRecord(events[ev++], stream); };
     static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
     static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
+    static const uint32_t envNodeMin = getenv("OKRT_FAST_NODE_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_NODE_MIN")) : 1u;
+    static const uint32_t envTriMin = getenv("OKRT_FAST_TRI_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_TRI_MIN")) : 1u;
     static const uint32_t envRefill = getenv("OKRT_FAST_REFILL") ? (uint32_t)atoi(getenv("OKRT_FAST_REFILL")) : (uint32_t)kRefillBelow;
     auto shards = [&](uint32_t b, bool camera) {
-        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
+        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, envNodeMin, envTriMin, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
                          fs.counts + kCursorBase + b * kShards * kCursorStride};
     };
     mark();
@@ -832,7 +852,7 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
-    const dim3 pg((unsigned)(fs.traceBlocks / 6 * envPacketBlocks));  // (29 VGPRs, 2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
+    const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (29 VGPRs, 2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
     if (packet && cnt)
         hipLaunchKernelGGL((tracePacketKernel<true>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
     else if (packet)
