@@ -64,7 +64,11 @@ struct Node2 {
 };
 
 constexpr int kBins = 16;
-static const uint32_t kLeafSize = getenv("OKRT_BUILD_LEAF") ? (uint32_t)atoi(getenv("OKRT_BUILD_LEAF")) : 4u;  // developer knob
+// Leaves: at most kLeafSize triangles; below that a range becomes a leaf as soon as testing all its triangles is no
+// dearer than the best split (SAH with a triangle test = 1, a BVH2 node = kNodeCost: the traversal kernel spends one
+// iteration on either, and a 4-wide node absorbs two to three BVH2 nodes). Developer knobs.
+static const uint32_t kLeafSize = getenv("OKRT_BUILD_LEAF") ? (uint32_t)atoi(getenv("OKRT_BUILD_LEAF")) : 6u;
+static const float kNodeCost = getenv("OKRT_BUILD_NODE_COST") ? (float)atof(getenv("OKRT_BUILD_NODE_COST")) : 1.f;  // < 0: leaves whenever count <= kLeafSize
 
 struct Builder {
     std::vector<Prim>& prims;
@@ -88,7 +92,7 @@ struct Builder {
         }
         n.box = bb;
         uint32_t cnt = hi - lo;
-        if (cnt <= kLeafSize) {
+        if (cnt <= 1 || (cnt <= kLeafSize && kNodeCost < 0.f)) {
             n.first = lo;
             n.count = cnt;
             return;
@@ -130,6 +134,11 @@ struct Builder {
                     bestBin = b;
                 }
             }
+        }
+        if (cnt <= kLeafSize && (bestAxis < 0 || (float)cnt * bb.area() <= kNodeCost * bb.area() + bestCost)) {
+            n.first = lo;
+            n.count = cnt;
+            return;
         }
         uint32_t mid;
         if (bestAxis < 0) {  // all centroids coincide: split the list in half

@@ -383,7 +383,11 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         leafWave += __shfl_down(leafWave, off, 64); leafLane += __shfl_down(leafLane, off, 64);
     }
     if (COUNT && counters && lane == 0) {  // cycle sums per wave: n_oct=refill, n_mesh=inner, n_node=leaf, n_tri=total, mesh_hits=#refills, sphere_hits=#iters, tex_taps=active lane-iters
+#ifdef OKRT_STAMPS_ITERS  // outer iterations and live lanes per iteration instead of the refill / leaf cycle sums
+        atomicAdd(&counters[2], laneIters); atomicAdd(&counters[3], tInner); atomicAdd(&counters[4], nIter);
+#else
         atomicAdd(&counters[2], tRefill); atomicAdd(&counters[3], tInner); atomicAdd(&counters[4], tLeaf);
+#endif
         atomicAdd(&counters[5], __builtin_amdgcn_s_memtime() - tStart);
         atomicAdd(&counters[6], nodeWave); atomicAdd(&counters[7], nodeLane); atomicAdd(&counters[8], leafWave); atomicAdd(&counters[9], leafLane);
     }
@@ -839,8 +843,8 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     auto mark = [&]() { if (events) hipEventRecord(events[ev++], stream); };
     static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
     static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
-    static const uint32_t envNodeMin = getenv("OKRT_FAST_NODE_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_NODE_MIN")) : 1u;
-    static const uint32_t envTriMin = getenv("OKRT_FAST_TRI_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_TRI_MIN")) : 1u;
+    static const uint32_t envNodeMin = getenv("OKRT_FAST_NODE_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_NODE_MIN")) : 32u;
+    static const uint32_t envTriMin = getenv("OKRT_FAST_TRI_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_TRI_MIN")) : 24u;
     static const uint32_t envRefill = getenv("OKRT_FAST_REFILL") ? (uint32_t)atoi(getenv("OKRT_FAST_REFILL")) : (uint32_t)kRefillBelow;
     auto shards = [&](uint32_t b, bool camera) {
         return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, envNodeMin, envTriMin, camera ? nullptr : fs.counts + b * kShards * kCursorStride,

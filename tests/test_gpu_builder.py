@@ -57,7 +57,7 @@ def check_structure(nodes, tris):
                 continue
             if c & LEAF:
                 first, count = c & 0x07FFFFFF, ((c >> 27) & 15) + 1
-                assert count <= 4 and first + count <= m
+                assert count <= 15 and first + count <= m
                 tri_refs[first:first + count] += 1
                 clo, chi = tlo[first:first + count].min(0), thi[first:first + count].max(0)
             else:

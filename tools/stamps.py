@@ -15,3 +15,5 @@ for mb in (1,):
           f"node loop: {c['mesh_hits']} wave-iterations, {c['sphere_hits']/max(c['mesh_hits'],1):.1f} active lanes each, {c['n_mesh']/max(c['mesh_hits'],1):.0f} cycles each | "
           f"leaf loop: {c['tex_taps']} wave-iterations, {c['env_taps']/max(c['tex_taps'],1):.1f} active lanes each, {c['n_node']/max(c['tex_taps'],1):.0f} cycles each | "
           f"nodes/ray {c['fast_nodes']/c['segments']:.1f} tris/ray {c['fast_tris']/c['segments']:.1f}")
+    if os.environ.get("OKRT_STAMPS_ITERS"):
+        print(f"   outer iterations {c['n_node']}, live lanes per iteration {c['n_oct']/max(c['n_node'],1):.1f}")
