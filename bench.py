@@ -264,14 +264,18 @@ def main():
     ctx.set_option(abi.OPT_TIMING, 0)
     rays_local = ctx.counters()["segments"]
     # for reference: the same frames issued one okrt_render call per frame (the reference's main-loop shape)
-    single_ms = None
+    single_ms = single_sync_ms = None
     if world == 1:
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(16):
-            rt.render()
-        ctx.synchronize()
-        single_ms = (time.perf_counter() - t1) * 1e3 / 16
+        def per_call(defer):
+            ctx.set_option(abi.OPT_DEFER, defer)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(32):
+                rt.render()
+            ctx.synchronize()
+            return (time.perf_counter() - t1) * 1e3 / 32
+        single_sync_ms = per_call(0)   # every okrt_render launches its own frame
+        single_ms = per_call(16)       # the default: the library defers and batches the accumulation loop's frames
 
     rays_total, elapsed_max = rays_local, elapsed
     if world > 1:
@@ -321,7 +325,7 @@ def main():
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl, "gpu_event_ms_per_step": round(ctx.timer_elapsed_ms() / max(steps_here, 1), 4), "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
+            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl, "gpu_event_ms_per_step": round(ctx.timer_elapsed_ms() / max(steps_here, 1), 4), "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None, "ms_per_step_one_call_per_frame_defer_off": round(single_sync_ms, 4) if single_sync_ms else None,
                        "tile_split": ("samples split: every rank renders the whole frame for its own block of frame indices" if samples_split else
                                       f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks") if world > 1 else "full frame",
                        "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "

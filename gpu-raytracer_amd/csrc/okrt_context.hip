@@ -51,6 +51,11 @@ struct okrt_ctx {
     bool fastDirty = true;
     bool fastGeometryDirty = true;  // t0 / t2 changed since the last build (device builder's leaf-range cache)
     uint32_t builder = 0;           // OKRT_OPT_BUILDER
+    // Deferred okrt_render calls (OKRT_OPT_DEFER): consecutive frames of an unchanged scene wait here and are traced by
+    // one launch set (renderImpl with frames > 1); anything that observes or changes state flushes them first.
+    uint32_t pending = 0, deferMax = 16;
+    okrt_render_data pendingRd{};
+    bool externalFramebuffers = false, externalStream = false;
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
     // OKRT_OPT_TIMING: ring of per-render event lists (kernel boundaries, in launch order)
     struct TimedFrame { std::vector<hipEvent_t> ev; int used = 0; bool fast = false; uint32_t frames = 1; };
@@ -59,12 +64,27 @@ struct okrt_ctx {
     std::string err;
 };
 
+static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames);  // below
+
 namespace {
 
 okrt_status fail(okrt_ctx* c, okrt_status s, const std::string& msg) {
     if (c) c->err = msg;
     return s;
 }
+
+// Executes the deferred frames. Errors of the launch (queue memory) surface at the call that flushes.
+okrt_status flushPending(okrt_ctx* c) {
+    if (!c->pending) return OKRT_OK;
+    const uint32_t n = c->pending;
+    c->pending = 0;
+    return renderImpl(c, &c->pendingRd, n);
+}
+#define OKRT_FLUSH(c)                                \
+    do {                                             \
+        okrt_status fs_ = flushPending(c);           \
+        if (fs_ != OKRT_OK) return fs_;              \
+    } while (0)
 #define OKRT_HIP(c, call)                                                                                   \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \
@@ -221,6 +241,7 @@ okrt_status okrt_create(int device, okrt_ctx** out) {
 
 okrt_status okrt_destroy(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    (void)flushPending(c);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (Table& t : c->tables)
@@ -248,6 +269,11 @@ okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint3
     Table& t = c->tables[slot];
     if (!data) count = 0;
     size_t bytes = (size_t)count * stride;
+    // RayTracer::updateBuffers re-uploads the light / sphere tables every frame (RayTracer.cpp:434-492): identical
+    // contents are not a change (and must not cut the deferred frames short)
+    if (t.stride == stride && t.count == count && bytes <= (64u << 10) && t.host.size() == bytes && (!bytes || std::memcmp(t.host.data(), data, bytes) == 0))
+        return OKRT_OK;
+    OKRT_FLUSH(c);
     okrt_status s = ensure(c, t.dev, bytes);
     if (s != OKRT_OK) return s;
     t.host.assign((const uint8_t*)data, (const uint8_t*)data + bytes);
@@ -284,6 +310,7 @@ okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint3
 
 okrt_status okrt_set_textures(okrt_ctx* c, const uint8_t* rgba8, uint32_t count, uint32_t width, uint32_t height) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     if (!rgba8 || !count || !width || !height) {
         okrt_status s = ensure(c, c->textures, 0);
@@ -303,6 +330,7 @@ okrt_status okrt_set_textures(okrt_ctx* c, const uint8_t* rgba8, uint32_t count,
 
 okrt_status okrt_set_envmap(okrt_ctx* c, const uint8_t* faces, uint32_t face) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     if (!faces || !face) {
         okrt_status s = ensure(c, c->env, 0);
@@ -344,6 +372,7 @@ okrt_status okrt_scale_texture_rgba8(okrt_ctx* c, const uint8_t* src, uint32_t s
 
 okrt_status okrt_resize(okrt_ctx* c, uint32_t width, uint32_t height) {
     if (!c || !width || !height || width > 65536 || height > 65536) return fail(c, OKRT_ERR_INVALID_ARG, "resize: bad dimensions");
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     c->W = width;
     c->H = height;
@@ -353,6 +382,7 @@ okrt_status okrt_resize(okrt_ctx* c, uint32_t width, uint32_t height) {
 
 okrt_status okrt_set_tile(okrt_ctx* c, uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_stride) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!c->W) return fail(c, OKRT_ERR_STATE, "set_tile before resize");
     if (!stripe_rows || !stripe_stride || stripe_index >= stripe_stride) return fail(c, OKRT_ERR_INVALID_ARG, "set_tile: bad stripe");
     OKRT_HIP(c, hipSetDevice(c->device));
@@ -368,26 +398,64 @@ okrt_status okrt_tile_rows(const okrt_ctx* c, uint32_t* out) {
 
 okrt_status okrt_bind_framebuffers(okrt_ctx* c, void* accum_dev, void* result_dev) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!c->W) return fail(c, OKRT_ERR_STATE, "bind_framebuffers before resize");
     c->accum = accum_dev ? (float4*)accum_dev : (float4*)c->accumOwn.ptr;
     c->result = result_dev ? (uint32_t*)result_dev : (uint32_t*)c->resultOwn.ptr;
+    c->externalFramebuffers = accum_dev || result_dev;  // the caller reads them in stream order: no deferral
     return OKRT_OK;
 }
 
 okrt_status okrt_reset_accumulation(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!c->accum) return OKRT_OK;
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipMemsetAsync(c->accum, 0, (size_t)c->tile.rows * c->W * sizeof(float4), c->stream));
     return OKRT_OK;
 }
 
-static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames);
+static okrt_status checkRenderArgs(okrt_ctx* c, const okrt_render_data* rd) {
+    if (!c->W) return fail(c, OKRT_ERR_STATE, "render before resize");
+    if (rd->textureDims[0] != c->W || rd->textureDims[1] != c->H) return fail(c, OKRT_ERR_INVALID_ARG, "render: textureDims differ from the resize dimensions");
+    if (rd->numSpheres > c->tables[OKRT_TABLE_SPHERE].count || rd->numDirLights > c->tables[OKRT_TABLE_DIR_LIGHT].count ||
+        rd->numPointLights > c->tables[OKRT_TABLE_POINT_LIGHT].count || rd->numSpotLights > c->tables[OKRT_TABLE_SPOT_LIGHT].count)
+        return fail(c, OKRT_ERR_RANGE, "render: a count in RenderData exceeds its uploaded table");
+    return OKRT_OK;
+}
+static okrt_status ensureTables(okrt_ctx* c);
+static okrt_status ensureFast(okrt_ctx* c);
 
-okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) { return renderImpl(c, rd, 1); }
+// One frame (RayTracer::render, RayTracer.cpp:219-260). With OKRT_OPT_DEFER (default) a frame that continues the
+// progressive accumulation of an unchanged scene is not launched at once: it joins the pending frames and is traced
+// together with them — by the next call that observes or changes anything, or when deferMax frames wait — with
+// framebuffers bit-identical to launching every frame on its own (test_render_frames_is_bit_identical...). Arguments
+// and tables are still validated here, so the call that passes bad data is the one that fails.
+okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
+    if (!c || !rd) return OKRT_ERR_INVALID_ARG;
+    const bool defer = c->deferMax > 1 && !c->externalFramebuffers && !c->externalStream && c->traversal == OKRT_TRAVERSAL_FAST &&
+                       rd->debugMode == 0 && rd->accumulationEnabled == 1;
+    if (!defer) {
+        OKRT_FLUSH(c);
+        return renderImpl(c, rd, 1);
+    }
+    okrt_status s = checkRenderArgs(c, rd);
+    if (s != OKRT_OK) return s;
+    OKRT_HIP(c, hipSetDevice(c->device));
+    if ((s = ensureTables(c)) != OKRT_OK || (s = ensureFast(c)) != OKRT_OK) return s;
+    if (c->pending) {
+        okrt_render_data expect = c->pendingRd;
+        expect.numAccumulationFrames += c->pending;  // the host's pre-increment per frame (RayTracer.cpp:489)
+        if (std::memcmp(&expect, rd, sizeof(expect)) != 0) OKRT_FLUSH(c);
+    }
+    if (!c->pending) c->pendingRd = *rd;
+    if (++c->pending >= c->deferMax) return flushPending(c);
+    return OKRT_OK;
+}
 
 okrt_status okrt_render_frames(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!frames) return OKRT_OK;
     const bool batchable = c->traversal == OKRT_TRAVERSAL_FAST && rd->debugMode == 0 && rd->accumulationEnabled == 1;
     okrt_render_data cur = *rd;
@@ -436,6 +504,7 @@ static okrt_status ensureFast(okrt_ctx* c) {
 
 okrt_status okrt_commit(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     okrt_status s = ensureTables(c);
     if (s != OKRT_OK) return s;
@@ -457,6 +526,7 @@ okrt_status okrt_get_build_info(okrt_ctx* c, okrt_build_info* out) {
 
 okrt_status okrt_get_fast_structure(okrt_ctx* c, void* nodes64, uint32_t node_capacity, void* tris48, uint32_t tri_capacity) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     std::string msg;
     if (c->fastDirty || !fastReadStructure(c->fast, nodes64, node_capacity, tris48, tri_capacity, c->stream, msg))
@@ -466,11 +536,8 @@ okrt_status okrt_get_fast_structure(okrt_ctx* c, void* nodes64, uint32_t node_ca
 
 static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
-    if (!c->W) return fail(c, OKRT_ERR_STATE, "render before resize");
-    if (rd->textureDims[0] != c->W || rd->textureDims[1] != c->H) return fail(c, OKRT_ERR_INVALID_ARG, "render: textureDims differ from the resize dimensions");
-    if (rd->numSpheres > c->tables[OKRT_TABLE_SPHERE].count || rd->numDirLights > c->tables[OKRT_TABLE_DIR_LIGHT].count ||
-        rd->numPointLights > c->tables[OKRT_TABLE_POINT_LIGHT].count || rd->numSpotLights > c->tables[OKRT_TABLE_SPOT_LIGHT].count)
-        return fail(c, OKRT_ERR_RANGE, "render: a count in RenderData exceeds its uploaded table");
+    okrt_status as = checkRenderArgs(c, rd);
+    if (as != OKRT_OK) return as;
     OKRT_HIP(c, hipSetDevice(c->device));
     okrt_status vs = ensureTables(c);
     if (vs != OKRT_OK) return vs;
@@ -521,6 +588,7 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
 
 okrt_status okrt_synchronize(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipStreamSynchronize(c->stream));
     return OKRT_OK;
@@ -528,6 +596,7 @@ okrt_status okrt_synchronize(okrt_ctx* c) {
 
 okrt_status okrt_read_result_rgba8(okrt_ctx* c, uint8_t* dst) {
     if (!c || !dst) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!c->result) return fail(c, OKRT_ERR_STATE, "read before resize");
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipMemcpyAsync(dst, c->result, (size_t)c->tile.rows * c->W * 4, hipMemcpyDeviceToHost, c->stream));
@@ -537,6 +606,7 @@ okrt_status okrt_read_result_rgba8(okrt_ctx* c, uint8_t* dst) {
 
 okrt_status okrt_read_accum_f32x4(okrt_ctx* c, float* dst) {
     if (!c || !dst) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!c->accum) return fail(c, OKRT_ERR_STATE, "read before resize");
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipMemcpyAsync(dst, c->accum, (size_t)c->tile.rows * c->W * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
@@ -546,6 +616,7 @@ okrt_status okrt_read_accum_f32x4(okrt_ctx* c, float* dst) {
 
 okrt_status okrt_write_accum_f32x4(okrt_ctx* c, const float* src) {
     if (!c || !src) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!c->accum) return fail(c, OKRT_ERR_STATE, "write before resize");
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipMemcpyAsync(c->accum, src, (size_t)c->tile.rows * c->W * sizeof(float4), hipMemcpyHostToDevice, c->stream));
@@ -555,6 +626,7 @@ okrt_status okrt_write_accum_f32x4(okrt_ctx* c, const float* src) {
 
 okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     switch (opt) {
         case OKRT_OPT_TRAVERSAL:
             if (value != OKRT_TRAVERSAL_REFERENCE && value != OKRT_TRAVERSAL_FAST) return fail(c, OKRT_ERR_INVALID_ARG, "traversal: 0 or 1");
@@ -565,6 +637,10 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             c->maxBounces = (int)value;
             return OKRT_OK;
         case OKRT_OPT_COUNTERS: c->countersOn = value != 0; return OKRT_OK;
+        case OKRT_OPT_DEFER:
+            if (value < 0 || value > (int64_t)kMaxFramesPerLaunch) return fail(c, OKRT_ERR_INVALID_ARG, "defer: 0 (off) .. 64 frames");
+            c->deferMax = (uint32_t)value;
+            return OKRT_OK;
         case OKRT_OPT_BUILDER:
             if (value != 0 && value != 1) return fail(c, OKRT_ERR_INVALID_ARG, "builder: 0 (host SAH) or 1 (device PLOC)");
             if ((uint32_t)value != c->builder) {
@@ -589,6 +665,7 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
 
 okrt_status okrt_get_counters(okrt_ctx* c, okrt_counters* out) {
     if (!c || !out) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     static_assert(sizeof(okrt_counters) == kNumCounters * sizeof(uint64_t), "counter layout");
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipMemcpyAsync(out, c->counters.ptr, sizeof(okrt_counters), hipMemcpyDeviceToHost, c->stream));
@@ -598,6 +675,7 @@ okrt_status okrt_get_counters(okrt_ctx* c, okrt_counters* out) {
 
 okrt_status okrt_reset_counters(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipMemsetAsync(c->counters.ptr, 0, c->counters.bytes, c->stream));
     return OKRT_OK;
@@ -605,20 +683,24 @@ okrt_status okrt_reset_counters(okrt_ctx* c) {
 
 okrt_status okrt_set_stream(okrt_ctx* c, void* hip_stream) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
+    c->externalStream = hip_stream != nullptr;  // the caller orders its own work after ours on that stream: no deferral
     return OKRT_OK;
 }
 
 okrt_status okrt_timer_begin(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipEventRecord(c->evBegin, c->stream));
     return OKRT_OK;
 }
 okrt_status okrt_timer_end(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipEventRecord(c->evEnd, c->stream));
     return OKRT_OK;
@@ -647,6 +729,7 @@ static okrt_status frameStages(okrt_ctx* c, const okrt_ctx::TimedFrame& f, float
 
 okrt_status okrt_last_render_ms(okrt_ctx* c, float* out_ms) {
     if (!c || !out_ms) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     if (!c->timingOn || !c->ringCount) return fail(c, OKRT_ERR_STATE, "last_render_ms: enable OKRT_OPT_TIMING before rendering");
     OKRT_HIP(c, hipSetDevice(c->device));
     const okrt_ctx::TimedFrame& f = c->ring[(c->ringNext + c->ring.size() - 1) % c->ring.size()];
@@ -658,6 +741,7 @@ okrt_status okrt_last_render_ms(okrt_ctx* c, float* out_ms) {
 
 okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames) {
     if (!c || !out_ms || !out_frames) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
     out_ms[0] = out_ms[1] = out_ms[2] = 0.f;
     *out_frames = 0;

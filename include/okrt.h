@@ -130,7 +130,15 @@ typedef enum okrt_option {
      *     4-wide nodes): the step the reference spends in BvhBuilder.cpp:72-97 / the octree rebuild of
      *     Application.cpp:312-317 on every scene edit, at interactive rates. Both cover exactly the triangles the
      *     reference shader reaches, so renders agree up to equal-distance ties. */
-    OKRT_OPT_BUILDER = 4
+    OKRT_OPT_BUILDER = 4,
+    /* n >= 2 (default 16): okrt_render calls that continue the progressive accumulation of an unchanged scene (same
+     * RenderData apart from numAccumulationFrames = previous + 1, fast traversal, no debug mode, library-owned stream
+     * and framebuffers) are deferred and up to n of them traced by one set of kernel launches — the reference's
+     * main loop `for (;;) render();` (Application.cpp:106-128) gets the throughput of okrt_render_frames without a
+     * change to the host. Every other entry point (read-backs, synchronize, uploads that change a table, options,
+     * timers, ...) executes the waiting frames first, so nothing can observe the deferral; the framebuffers are
+     * bit-identical to immediate execution. 0 or 1 = launch every frame inside its own okrt_render. */
+    OKRT_OPT_DEFER = 5
 } okrt_option;
 
 #define OKRT_BUILDER_HOST 0

@@ -228,3 +228,32 @@ def test_checkpoint_resume_is_bit_identical():
     rt2.renderFrames(2)
     assert np.array_equal(rt2.ctx.read_accum(), full, equal_nan=True)
     rt2.close()
+
+
+def test_deferred_frames_are_bit_identical_and_unobservable():
+    """OKRT_OPT_DEFER: okrt_render calls of the accumulation loop wait and are traced together. Same framebuffers as
+    immediate execution, also when the loop is interrupted by what a host does between frames: re-uploading unchanged
+    light tables (RayTracer::updateBuffers does, every frame), a real table change, a read-back, a DOF edit."""
+    desc = scenes.small_mesh_scene(seed=9, n_objects=6, detail=10, with_lights=True)
+
+    def run(defer):
+        rt, sc, res = scenes.instantiate(desc, 256, 144)
+        rt.ctx.set_option(abi.OPT_DEFER, defer)
+        snaps = []
+        for i in range(23):
+            rt.render()  # host layer: updateBuffers (light/sphere tables re-uploaded, identical) + okrt_render
+            if i == 4:
+                snaps.append(rt.ctx.read_accum().copy())  # a read-back in the middle of a deferred run
+            if i == 9:
+                rt.setDOF(0.5, 12.0)  # RenderData changes: the waiting frames must be traced with the old one
+            if i == 15:
+                snaps.append(rt.ctx.counters()["pixels"])
+        snaps.append(rt.ctx.read_accum().copy())
+        snaps.append(rt.ctx.read_result().copy())
+        rt.close()
+        return snaps
+
+    a, b = run(16), run(0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True) if isinstance(x, np.ndarray) and x.dtype.kind == "f" else np.array_equal(x, y)
+    assert a[2][..., 3].max() == 23  # alpha counts frames: nothing was lost at the end of the loop
