@@ -41,7 +41,7 @@ namespace {
 constexpr int kBT = 256;              // threads per block of every build kernel
 constexpr int kRadius = 16;           // PLOC search radius (default)
 constexpr int kMaxRadius = 64;
-constexpr uint32_t kLeafTris = 4;     // leaves hold <= 4 triangles (as the host build)
+constexpr uint32_t kLeafTris = 6;     // leaves hold <= 6 triangles, decided by the host build's SAH rule (leafLike)
 constexpr uint32_t kIdentityBit = 0x80000000u;
 
 struct alignas(16) Node2D {  // BVH2 node: two float4
@@ -438,7 +438,21 @@ __device__ __forceinline__ void emitTri(const float4* __restrict__ prims, uint32
     tris[3 * (size_t)slot + 2] = make_float4(p1.x - p2.x, p1.y - p2.y, p1.z - p2.z, 0.f);          // E2 = p1 - p2
 }
 
-// One queue item = (Node4Q slot, BVH2 node with more than kLeafTris triangles below it).
+// The host build's leaf rule (okrt_fast_build.cpp): a subtree of <= kLeafTris triangles becomes a leaf when testing them
+// all costs no more than one more node + its two halves (triangle test = node visit = 1).
+__device__ __forceinline__ bool leafLike(const Node2D* __restrict__ nodes, const uint32_t* __restrict__ cnt, uint32_t id, uint32_t c) {
+    if (c > kLeafTris) return false;
+    if (c <= 1u) return true;
+    const Node2D& n = nodes[id];
+    const Node2D& l = nodes[n.left];
+    const Node2D& r = nodes[n.right];
+    const float A = halfArea(n.mx[0] - n.mn[0], n.mx[1] - n.mn[1], n.mx[2] - n.mn[2]);
+    const float split = halfArea(l.mx[0] - l.mn[0], l.mx[1] - l.mn[1], l.mx[2] - l.mn[2]) * (float)cnt[n.left] +
+                        halfArea(r.mx[0] - r.mn[0], r.mx[1] - r.mn[1], r.mx[2] - r.mn[2]) * (float)cnt[n.right];
+    return (float)c * A <= A + split;
+}
+
+// One queue item = (Node4Q slot, BVH2 node that is not leafLike).
 __global__ __launch_bounds__(kBT) void collapseKernel(const Node2D* __restrict__ nodes, const uint32_t* __restrict__ cnt, uint32_t numPrims,
                                                       const float4* __restrict__ prims, const uint2* __restrict__ queueIn, uint32_t numIn,
                                                       uint2* __restrict__ queueOut, Counters* __restrict__ counters, uint4* __restrict__ outNodes,
@@ -446,6 +460,7 @@ __global__ __launch_bounds__(kBT) void collapseKernel(const Node2D* __restrict__
     const uint32_t t = blockIdx.x * kBT + threadIdx.x;
     const bool active = t < numIn;
     uint32_t kids[4] = {0, 0, 0, 0}, kc[4] = {0, 0, 0, 0};
+    bool kl[4] = {false, false, false, false};  // kid is emitted as a leaf
     float bmn[4][3], bmx[4][3];
     int n = 0;
     uint32_t slot = 0, needNodes = 0, needTris = 0;
@@ -455,26 +470,29 @@ __global__ __launch_bounds__(kBT) void collapseKernel(const Node2D* __restrict__
         kids[0] = nodes[item.y].left;
         kids[1] = nodes[item.y].right;
         n = 2;
-        for (int i = 0; i < 2; ++i) kc[i] = cnt[kids[i]];
+        for (int i = 0; i < 2; ++i) {
+            kc[i] = cnt[kids[i]];
+            kl[i] = leafLike(nodes, cnt, kids[i], kc[i]);
+        }
         while (n < 4) {  // open the inner child with the largest area
             int pick = -1;
             float best = -1.f;
             for (int i = 0; i < n; ++i) {
-                if (kc[i] <= kLeafTris) continue;
+                if (kl[i]) continue;
                 const Node2D& c = nodes[kids[i]];
                 const float ar = halfArea(c.mx[0] - c.mn[0], c.mx[1] - c.mn[1], c.mx[2] - c.mn[2]);
                 if (ar > best) { best = ar; pick = i; }
             }
             if (pick < 0) break;
             const uint32_t l = nodes[kids[pick]].left, r = nodes[kids[pick]].right;
-            kids[pick] = l; kc[pick] = cnt[l];
-            kids[n] = r; kc[n] = cnt[r];
+            kids[pick] = l; kc[pick] = cnt[l]; kl[pick] = leafLike(nodes, cnt, l, kc[pick]);
+            kids[n] = r; kc[n] = cnt[r]; kl[n] = leafLike(nodes, cnt, r, kc[n]);
             ++n;
         }
         for (int i = 0; i < n; ++i) {
             const Node2D& c = nodes[kids[i]];
             for (int a = 0; a < 3; ++a) { bmn[i][a] = c.mn[a]; bmx[i][a] = c.mx[a]; }
-            if (kc[i] <= kLeafTris) needTris += kc[i]; else needNodes += 1;
+            if (kl[i]) needTris += kc[i]; else needNodes += 1;
         }
     }
     uint32_t nodeBase = waveAlloc(&counters[kCntNode4].v[0], needNodes);
@@ -484,7 +502,7 @@ __global__ __launch_bounds__(kBT) void collapseKernel(const Node2D* __restrict__
     uint32_t refs[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
     uint32_t q = queueBase;
     for (int i = 0; i < n; ++i) {
-        if (kc[i] <= kLeafTris) {
+        if (kl[i]) {
             const uint32_t first = triBase;
             uint32_t st[8];
             int sp = 0;
