@@ -193,9 +193,32 @@ OKRT_DEV V3 rcp3(V3 d) { return mk(1.f / d.x, 1.f / d.y, 1.f / d.z); }
 // restated by the oracle): texel centres at +0.5, exact fp32 weights, UNORM8 = c/255,
 // lerp(lerp(t00,t10,fx), lerp(t01,t11,fx), fy). Texture2DArray: WRAP (RayTracer.cpp:99-109),
 // slice = round-half-even(idx) clamped. TextureCube: v_cubeid face rule, clamp inside the face.
+// c / 255.f for c = 0..255, correctly rounded, without the 10-instruction IEEE division sequence: one Newton step on
+// q = c * fl(1/255) is exact for all 256 inputs (checked exhaustively against the division: tests/test_abi.py).
+OKRT_DEV float unorm8(uint32_t c) {
+    const float r = 1.0f / 255.0f, fc = (float)c;
+    const float q = fc * r;
+    return fma_(fma_(-q, 255.f, fc), r, q);
+}
 OKRT_DEV V3 texel(const uint8_t* p) {
     uint32_t w = *reinterpret_cast<const uint32_t*>(p);
-    return mk((float)(w & 255u) / 255.f, (float)((w >> 8) & 255u) / 255.f, (float)((w >> 16) & 255u) / 255.f);
+    return mk(unorm8(w & 255u), unorm8((w >> 8) & 255u), unorm8((w >> 16) & 255u));
+}
+// a - floor(a / n) * n for the WRAP address mode; a division by a power of two is an exact multiplication
+OKRT_DEV float wrapFloor(float a, int n) {
+    const float fn = (float)n;
+    // 1 / 2^k by exponent arithmetic (exact): bits(2^-k) = (254 << 23) - bits(2^k)
+    const float q = (n & (n - 1)) == 0 ? a * __uint_as_float((254u << 23) - __float_as_uint(fn)) : a / fn;
+    return a - floorf(q) * fn;
+}
+// (int)w % n folded into [0, n): w already lies in [0, n] after wrapFloor except for non-finite / huge coordinates
+OKRT_DEV int wrapIndex(float w, int n) {
+    int i = (int)w;
+    if ((unsigned)i >= (unsigned)n) {
+        i %= n;
+        if (i < 0) i += n;
+    }
+    return i;
 }
 OKRT_DEV V3 bilerp(V3 t00, V3 t10, V3 t01, V3 t11, float fx, float fy) {
     return lerp(lerp(t00, t10, fx), lerp(t01, t11, fx), fy);
@@ -211,10 +234,8 @@ OKRT_DEV V3 sampleTexture(const SceneView& s, uint32_t textureIdx, float u, floa
     float x = fma_(u, (float)W, -0.5f), y = fma_(v, (float)H, -0.5f);
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;
-    float wx = fx0 - floorf(fx0 / (float)W) * (float)W;
-    float wy = fy0 - floorf(fy0 / (float)H) * (float)H;
-    int x0 = (int)wx % W; if (x0 < 0) x0 += W;
-    int y0 = (int)wy % H; if (y0 < 0) y0 += H;
+    float wx = wrapFloor(fx0, W), wy = wrapFloor(fy0, H);
+    int x0 = wrapIndex(wx, W), y0 = wrapIndex(wy, H);
     int x1 = x0 + 1 == W ? 0 : x0 + 1;
     int y1 = y0 + 1 == H ? 0 : y0 + 1;
     const uint8_t* base = s.textures + (size_t)slice * W * H * 4;

@@ -307,3 +307,14 @@ def test_cube_faces_follow_the_d3d_table(oracle):
     lib.okrt_oracle_kat_sample_env(ctx.h, f3(0, 1, 0), out)
     assert list(out) == [0, 0, 0]
     ctx.close()
+
+
+def test_unorm8_newton_step_is_exact():
+    """csrc/okrt_device.h unorm8(): c * fl(1/255) followed by one fma Newton step equals the correctly rounded c / 255.f
+    for every 8-bit value (the device code decodes texels this way; the oracle divides)."""
+    c = np.arange(256, dtype=np.float64)
+    r = np.float64(np.float32(1.0) / np.float32(255.0))
+    q = (c * r).astype(np.float32).astype(np.float64)               # fl32(c * r)
+    e = (c - q * 255.0).astype(np.float32).astype(np.float64)       # fma(-q, 255, c): the product is exact in f64
+    v = (e * r + q).astype(np.float32)                              # fma(e, r, q)
+    assert np.array_equal(v, np.arange(256, dtype=np.float32) / np.float32(255.0))
