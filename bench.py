@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-call", action="store_true", help="skip the one-okrt_render-per-frame timing (profiling runs: every launch set then has frames_per_launch frames)")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
     ap.add_argument("--split", default="tiles", choices=["tiles", "samples"],
                     help="N > 1: 'tiles' = image-space stripes + gather (the north-star path); 'samples' = every rank renders "
@@ -265,7 +266,7 @@ def main():
     rays_local = ctx.counters()["segments"]
     # for reference: the same frames issued one okrt_render call per frame (the reference's main-loop shape)
     single_ms = single_sync_ms = None
-    if world == 1:
+    if world == 1 and not args.no_single_call:
         def per_call(defer):
             ctx.set_option(abi.OPT_DEFER, defer)
             ctx.synchronize()
@@ -331,7 +332,7 @@ def main():
                        "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "
                                   f"every {GATHER_EVERY} frames + final") if world > 1 else "none"},
             "roofline": {
-                "bound": "hbm", "kernel": "generateKernel + traceKernel (BVH traversal, all segments of one frame), per GPU",
+                "bound": "hbm", "kernel": "generateKernel + tracePacketKernel (camera rays) + traceKernel (bounce rays): BVH traversal of all segments of one frame, per GPU",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
                 "algorithmic_bytes_per_frame": trav_bytes, "algorithmic_bytes_per_ray": round(trav_bytes / max(ref_counters["segments"], 1), 1),
