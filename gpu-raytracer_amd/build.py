@@ -66,9 +66,22 @@ def build_oracle():
         _run(["make", "-C", os.path.join(REPO, "oracle"), "ref"])
 
 
+def build_examples(force=False):
+    """examples/headless_host: a C++ host linked against the host layer and the device layer (no Python in between)."""
+    src = os.path.join(REPO, "examples", "headless_host.cpp")
+    out = os.path.join(REPO, "examples", "headless_host")
+    deps = [src, os.path.join(PKG, "libokrt.so"), os.path.join(PKG, "libokrt_host.so")] + glob.glob(os.path.join(PKG, "host", "*.h"))
+    if force or _newer(out, deps):
+        _run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-ffp-contract=off", src, "-I" + os.path.join(REPO, "include"),
+              "-I" + os.path.join(PKG, "host"), "-L" + PKG, "-lokrt_host", "-lokrt", "-L/opt/rocm/lib", "-lamdhip64",
+              "-Wl,-rpath,$ORIGIN/../gpu-raytracer_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    return out
+
+
 def build_all(force=False):
     build_device(force)
     build_host(force)
+    build_examples(force)
     build_oracle()
 
 

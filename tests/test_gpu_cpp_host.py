@@ -1,0 +1,79 @@
+"""examples/headless_host.cpp — a C++ host in the shape of the reference's Application, linked against the host layer and
+libokrt.so with no Python in between — must produce, byte for byte, the image the Python binding produces for the same
+scene (same host-layer code, same device code; this pins the link-level drop-in and the one-render()-per-frame loop)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import abi, host, scenes
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(REPO, "examples", "headless_host")
+F32 = np.float32
+
+
+def python_scene():
+    """The scene of headless_host.cpp, built value for value through the Python binding."""
+    P = np.array([[2, 0, 0], [-2, 0, 0], [0, 2, 0], [0, -2, 0], [0, 0, 2], [0, 0, -2]], F32)
+    F = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    pos = np.zeros((8, 3, 3), F32)
+    info = np.zeros((8, 3, 11), F32)
+    third = F32(1.0) / F32(3.0)
+    for t, f in enumerate(F):
+        n = np.zeros(3, F32)
+        for v in range(3):
+            n = (n + P[f[v]] * third).astype(F32)
+        for v in range(3):
+            pos[t, v] = P[f[v]]
+            info[t, v] = [n[0], n[1], n[2], 1.0 if v == 1 else 0.0, 1.0 if v == 2 else 0.0, 1, 0, 0, 0, 1, 0]
+    tex = np.zeros((16, 16, 4), np.uint8)
+    for y in range(16):
+        for x in range(16):
+            c = 230 if ((x // 4 + y // 4) & 1) else 40
+            tex[y, x] = (c, 255 - c, 128, 255)
+    res = host.ResourceManager()
+    mesh = res.add_mesh(pos.reshape(8, 9), info.reshape(8, 33))
+    tex_id = res.add_texture(tex)
+    sc = host.Scene()
+    d = lambda a, b: float(F32(a) / F32(b))  # noqa: E731  (the C++ literals divide in float)
+    spheres = [((-81.3, -1109.9, 18.0), 1109.8, (1.0, d(179, 255), d(128, 255)), (1, 1, 1), 0.0),
+               ((-4.0, 0.4, 20.0), 3.2, (1, 1, 1), (1, 1, 1), 0.0),
+               ((105.5, 71.6, 118.0), 81.0, (1, 1, 1), (d(223, 255), d(168, 255), d(81, 255)), 4.95),
+               ((106.0, 700.6, -290.1), 680.0, (0, 0, 0), (1, 1, 1), 0.0)]
+    for p, r, albedo, emit, power in spheres:
+        sc.add_sphere(sc.create_entity(p), r, host.Material(albedo=albedo, emissionColour=emit, emissionPower=power))
+    e = sc.create_entity((3.0, 3.5, 17.0), (20.0, 35.0, 0.0))
+    sc.add_mesh(e, mesh, host.Material(albedo=(1, 1, 1), albedoTextureId=tex_id, roughness=0.4))
+    sc.add_camera(sc.create_entity((1.2, 4.1, 10.1), (19.4, -10.9, 0.0)))
+    return res, sc
+
+
+@pytest.mark.parametrize("device_builder", [0, 1])
+def test_cpp_host_matches_the_python_binding(tmp_path, device_builder):
+    assert os.path.exists(EXE), "examples/headless_host is missing: python -c 'import __graft_entry__ as g; g.build()'"
+    W, H, frames = 320, 180, 20
+    out = tmp_path / "cpp.ppm"
+    run = subprocess.run([EXE, str(W), str(H), str(frames), str(out), str(device_builder)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    assert f"numAccumulationFrames {frames}" in run.stdout and ("the device" if device_builder else "the host") in run.stdout
+    raw = out.read_bytes()
+    header = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(header)
+    cpp = np.frombuffer(raw[len(header):], np.uint8).reshape(H, W, 3)
+
+    res, sc = python_scene()
+    rt = host.RayTracer()
+    rt.initiate(W, H, res)
+    rt.setScene(sc)
+    rt.createOctTree(sc, 0, 50)
+    rt.ctx.set_option(abi.OPT_BUILDER, device_builder)
+    for _ in range(frames):
+        rt.render()
+    py = rt.ctx.read_result()[..., :3]
+    rt.close()
+    assert cpp.std() > 10  # a real image
+    assert np.array_equal(cpp, py)
