@@ -2,12 +2,13 @@
 //
 // One frame = a short pipeline of kernels over ray queues in HBM (per path segment):
 //
-//   generateKernel         camera rays for the owned pixels, in 8x8-tile order, into ray queue 0 (32 B per ray)
-//   traceKernel            persistent waves: closest hit through the Node4Q/Tri48 structure for every ray of
-//                          the queue, hit record (20 B) written per ray
-//   shadeKernel            material/texture fetch, lights, BSDF sample; finished paths accumulate into the
-//                          framebuffer, survivors are compacted into the next ray queue (56 B per ray)
-//   traceKernel / shadeKernel   ... one pair per further segment
+//   generateKernel         camera rays for the owned pixels of F frames, in 8x8-tile order, into ray queue 0 (32 B per ray)
+//   tracePacketKernel      camera rays: one wave walks the tree once for its 8x8 tile (wave-uniform node, scalar loads)
+//   traceKernel            every other segment: persistent waves, one node visit or triangle test per lane and
+//                          iteration ("if-if"), closest hit through the Node4Q/Tri48 structure, 20-byte hit record per ray
+//   shadeKernel            material/texture fetch, lights, BSDF sample; finished paths go to the framebuffer (or their
+//                          frame's radiance slot), survivors are compacted into the next ray queue (56 B per ray)
+//   traceKernel / shadeKernel   ... one pair per further segment;  accumulateKernel when F > 1
 //
 // Traversal (what the profile is dominated by) is built for CDNA4:
 //   * wave64, 256-thread blocks, persistent: each wave REFILLS its idle lanes when fewer than
@@ -21,7 +22,8 @@
 //     entry distance so stale entries are dropped without touching memory; deeper levels spill to
 //     a per-thread HBM slab (sized from the tree depth at build time);
 //   * one Node4Q visit = 4 x 16-byte loads (64 B, 8-bit child planes on a per-node grid, conservative);
-//     children are visited nearest first (4-key sorting network), a Tri48 test = 3 x 16-byte loads;
+//     children are visited nearest first (4-key sorting network), a Tri48 test = 3 x 16-byte loads; a lane does
+//     one of the two per iteration and the loads of all lanes are issued together (see the loop body);
 //   * same arithmetic as the reference for what decides the result: the ray re-normalised as the
 //     shader does for each instance, Moeller-Trumbore with the
 //     shader's edge convention, hit distance = length(dir*t) (RaytracerCS.hlsl:276,285,306-316),
@@ -432,18 +434,25 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
     uint32_t shard = sv.xcdAffinity ? (xcc & (kShards - 1)) : 0u, tried = 0;
     uint32_t nNodes = 0, nTris = 0, nSeg = 0;
 
-    for (;;) {
-        // ---- next tile: 64 positions from this XCD's shard, stealing when it is dry (all wave-uniform) -----------
-        uint32_t base = kInvalid;
+    // Tile fetch, software-pipelined two deep: the reservation (a returning atomic on the shard cursor, ~1.5 us) for the
+    // tile after next is in flight while the next tile's rays are being loaded and the current tile is traversed.
+    uint32_t preRaw = 0, preShard = 0;  // preRaw is only meaningful in lane 0
+    bool havePre = false;
+    auto acquire = [&]() -> uint32_t {  // wave-uniform: first queue position of the next tile, kInvalid when all shards are dry
         while (tried < kShards) {
-            const uint32_t cnt = sv.count(shard);
-            uint32_t bpos = 0;
-            if (lane == 0) bpos = atomicAdd(&sv.cursors[shard * kCursorStride], 64u);
-            bpos = __builtin_amdgcn_readfirstlane(bpos);
+            if (!havePre) {
+                if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], 64u);
+                preShard = shard;
+            }
+            havePre = false;
+            const uint32_t bpos = __builtin_amdgcn_readfirstlane(preRaw);  // waits for the atomic here
+            const uint32_t cnt = sv.count(preShard);
             if (bpos < cnt) {
-                base = shard * sv.cap + bpos;
                 tried = 0;
-                break;
+                if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], 64u);  // the one after: consumed a tile later
+                preShard = shard;
+                havePre = true;
+                return preShard * sv.cap + bpos;
             }
             uint32_t seen = 0xFFFFFFFFu, lim = 0;
             if (lane < kShards) {
@@ -459,10 +468,29 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
             shard = (shard + (uint32_t)__builtin_ctz(rot)) & (kShards - 1);
             tried++;
         }
-        if (base == kInvalid) break;
-
+        return kInvalid;
+    };
+    uint32_t base = acquire();
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
+    if (base != kInvalid) {
+        A = q.a[base + lane];
+        B = q.b[base + lane];
+    }
+    uint32_t nextBase = kInvalid;
+    float4 nA = A, nB = B;
+#ifdef OKRT_STAMPS
+    unsigned long long pT0 = __builtin_amdgcn_s_memtime(), pSetup = 0, pNode = 0, pLeaf = 0, pTiles = 0, pNodeSteps = 0, pLeafTris = 0, pMark = pT0;
+#define OKRT_PMARK(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - pMark; pMark = n_; }
+#else
+#define OKRT_PMARK(acc)
+#endif
+    for (; base != kInvalid; base = nextBase, A = nA, B = nB) {  // (the hand-over sits at the END of an iteration: no early wait)
         const uint32_t mine = base + lane;
-        const float4 A = q.a[mine], B = q.b[mine];
+        nextBase = acquire();
+        if (nextBase != kInvalid) {  // in flight during the traversal below
+            nA = q.a[nextBase + lane];
+            nB = q.b[nextBase + lane];
+        }
         Ray ray;
         ray.origin = mk(A.x, A.y, A.z);
         ray.direction = mk(A.w, B.x, B.y);
@@ -486,9 +514,16 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
             }
 
         uint32_t sp = 0, cur = 0;  // wave-uniform
+#ifdef OKRT_STAMPS
+        pTiles++;
+#endif
+        OKRT_PMARK(pSetup)
         for (;;) {
             cur = __builtin_amdgcn_readfirstlane(cur);
             if (!(cur & kLeafBit)) {
+#ifdef OKRT_STAMPS
+                pNodeSteps++;
+#endif
                 const uint4* np = nodes + (size_t)cur * 4;  // uniform address: scalar loads
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 if (COUNT) nNodes++;
@@ -527,12 +562,16 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
                         if (lane == 0) stack[sp] = ref[k];
                         sp++;
                     }
+                OKRT_PMARK(pNode)
                 if (key[0] != 0xFFFFFFFFu) {
                     cur = ref[0];
                     continue;
                 }
             } else {
                 const uint32_t count = ((cur >> 27) & 15u) + 1u;
+#ifdef OKRT_STAMPS
+                pLeafTris += count;
+#endif
                 const float4* tp = tris + (size_t)(cur & 0x07FFFFFFu) * 3;  // uniform address: scalar loads
                 for (uint32_t j = 0; j < count; ++j, tp += 3) {
                     const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
@@ -551,6 +590,7 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
                     }
                 }
             }
+            OKRT_PMARK(pLeaf)
             if (sp == 0) break;
             --sp;
             cur = stack[sp];  // same address in every lane (broadcast); written by lane 0 above
@@ -560,6 +600,13 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
             hb.tri[mine] = hitTri;
         }
     }
+#ifdef OKRT_STAMPS
+    if (COUNT && counters && lane == 0) {  // n_oct=setup cycles, n_mesh=node, n_node=leaf+pop, n_tri=total, mesh_hits=tiles, sphere_hits=node steps, tex_taps=leaf triangles
+        atomicAdd(&counters[2], pSetup); atomicAdd(&counters[3], pNode); atomicAdd(&counters[4], pLeaf);
+        atomicAdd(&counters[5], __builtin_amdgcn_s_memtime() - pT0);
+        atomicAdd(&counters[6], pTiles); atomicAdd(&counters[7], pNodeSteps); atomicAdd(&counters[8], pLeafTris);
+    }
+#endif
     if (COUNT && counters) {
         uint32_t v = nSeg;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -6,10 +6,16 @@ abi = importlib.import_module("gpu-raytracer_amd._abi"); scenes = importlib.impo
 desc = scenes.sponza_proxy()
 rt, sc, res = scenes.instantiate(desc, 1920, 1080)
 FRAMES = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-for mb in (1,):
+for mb in ((0, 1) if os.environ.get('OKRT_STAMPS_PACKET') else (1,)):
     rt.ctx.set_option(abi.OPT_MAX_BOUNCES, mb)
     rt.resetAccumulation(); rt.render(); rt.render()
     rt.ctx.set_option(abi.OPT_COUNTERS, 1); rt.ctx.reset_counters(); rt.renderFrames(FRAMES); c = rt.ctx.counters(); rt.ctx.set_option(abi.OPT_COUNTERS, 0)
+    if mb == 0:
+        tot = c["n_tri"]
+        print(f"packet kernel: wave-cycles {tot:.3e}: setup {c['n_oct']/tot:.3f} node {c['n_mesh']/tot:.3f} leaf+pop {c['n_node']/tot:.3f} | tiles {c['mesh_hits']} "
+              f"node steps/tile {c['sphere_hits']/max(c['mesh_hits'],1):.1f} ({c['n_mesh']/max(c['sphere_hits'],1):.0f} cycles each) leaf tris/tile {c['tex_taps']/max(c['mesh_hits'],1):.1f} "
+              f"({c['n_node']/max(c['tex_taps'],1):.0f} cycles each incl. pops) setup {c['n_oct']/max(c['mesh_hits'],1):.0f} cycles/tile")
+        continue
     tot = c["n_tri"]
     print(f"max_bounces={mb} segments {c['segments']} wave-cycles total {tot:.3e}: refill {c['n_oct']/tot:.3f} node loop {c['n_mesh']/tot:.3f} leaf {c['n_node']/tot:.3f} | "
           f"node loop: {c['mesh_hits']} wave-iterations, {c['sphere_hits']/max(c['mesh_hits'],1):.1f} active lanes each, {c['n_mesh']/max(c['mesh_hits'],1):.0f} cycles each | "
