@@ -48,6 +48,29 @@ def algorithmic_bytes(c):
     return traversal, shading
 
 
+def usable_cpus():
+    """Threads worth starting: the CPU count, cut down to the scheduler affinity and the cgroup quota (a one-GPU box
+    shows 256 CPUs but grants its job a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
     """The scalar oracle (oracle/liboracle.so) on the host cores, on a bounded sample of the same frame:
     every `stride`-th row, stride chosen from a short calibration run to cost about `target_seconds`."""
@@ -58,7 +81,7 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
     rt.calculateProjectionData()
     rt.updateBuffers()
     rd = rt.render_data
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     abi = conftest.abi
 
     def run(stride):
@@ -70,10 +93,10 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
         dt = time.perf_counter() - t0
         return rt.ctx.counters()["segments"], dt, rt.ctx.tile_rows()
 
-    # one thread first ("report 1-thread and all-thread"): ~8 rows spread over the frame
+    # one thread first ("report 1-thread and all-thread"): ~64 rows spread over the frame
     oracle.lib.okrt_oracle_set_threads(rt.ctx.h, 1)
-    rays1, dt1, rows1 = run(max(height // 8, 1))
-    oracle.lib.okrt_oracle_set_threads(rt.ctx.h, 0)  # 0 = hardware_concurrency
+    rays1, dt1, rows1 = run(max(height // 64, 1))
+    oracle.lib.okrt_oracle_set_threads(rt.ctx.h, cores)
     rays, dt, rows = run(max(height // 16, 1))  # calibration: ~16 rows
     rate = rays / max(dt, 1e-6)
     full_rays = rays * (height / max(rows, 1))
