@@ -251,8 +251,8 @@ def main():
     # A step is one frame. Frames are handed to the device layer F at a time (okrt_render_frames): same framebuffers
     # bit for bit, but one set of kernel launches traces F frames' rays, which amortises the per-launch latency floor
     # (the longest ray's dependent steps) — decisive when a rank only owns 1/N of the pixels.
-    # default: 16 frames per launch set on one GPU; with N ranks each owns 1/N of the pixels, so 64 (= the gather period)
-    fpl = args.frames_per_launch or int(os.environ.get("OKRT_BENCH_FPL", "0")) or (16 if world == 1 else 64)
+    # default: 64 frames per launch set (= the gather period with N ranks)
+    fpl = args.frames_per_launch or int(os.environ.get("OKRT_BENCH_FPL", "0")) or 64
     gather_every = int(os.environ.get("OKRT_BENCH_GATHER_EVERY", GATHER_EVERY))
     fpl = max(1, min(fpl, 64, gather_every))
 
@@ -294,12 +294,12 @@ def main():
             ctx.set_option(abi.OPT_DEFER, defer)
             ctx.synchronize()
             t1 = time.perf_counter()
-            for _ in range(32):
+            for _ in range(64):
                 rt.render()
             ctx.synchronize()
-            return (time.perf_counter() - t1) * 1e3 / 32
+            return (time.perf_counter() - t1) * 1e3 / 64
         single_sync_ms = per_call(0)   # every okrt_render launches its own frame
-        single_ms = per_call(16)       # the default: the library defers and batches the accumulation loop's frames
+        single_ms = per_call(32)       # the default: the library defers and batches the accumulation loop's frames
 
     rays_total, elapsed_max = rays_local, elapsed
     if world > 1:

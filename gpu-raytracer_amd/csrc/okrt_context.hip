@@ -53,7 +53,8 @@ struct okrt_ctx {
     uint32_t builder = 0;           // OKRT_OPT_BUILDER
     // Deferred okrt_render calls (OKRT_OPT_DEFER): consecutive frames of an unchanged scene wait here and are traced by
     // one launch set (renderImpl with frames > 1); anything that observes or changes state flushes them first.
-    uint32_t pending = 0, deferMax = 16;
+    uint32_t pending = 0, deferMax = 32;
+    uint32_t batchLimit = kMaxFramesPerLaunch;  // halved when the queues of a launch set do not fit in memory
     okrt_render_data pendingRd{};
     bool externalFramebuffers = false, externalStream = false;
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
@@ -74,11 +75,29 @@ okrt_status fail(okrt_ctx* c, okrt_status s, const std::string& msg) {
 }
 
 // Executes the deferred frames. Errors of the launch (queue memory) surface at the call that flushes.
+// `frames` consecutive frames of the accumulation loop, as few launch sets as memory allows: a launch set that cannot
+// get its queues (56+ bytes per ray and frame) is retried at half the size, and the limit is remembered.
+okrt_status renderBatched(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames, bool batchable) {
+    okrt_render_data cur = *rd;
+    while (frames) {
+        const uint32_t n = batchable ? std::min<uint32_t>(frames, c->batchLimit) : 1u;
+        const okrt_status s = renderImpl(c, &cur, n);
+        if (s == OKRT_ERR_OOM && n > 1) {
+            c->batchLimit = n / 2;
+            continue;
+        }
+        if (s != OKRT_OK) return s;
+        if (cur.accumulationEnabled == 1) cur.numAccumulationFrames += n;  // the host's pre-increment per frame (RayTracer.cpp:489)
+        frames -= n;
+    }
+    return OKRT_OK;
+}
+
 okrt_status flushPending(okrt_ctx* c) {
     if (!c->pending) return OKRT_OK;
     const uint32_t n = c->pending;
     c->pending = 0;
-    return renderImpl(c, &c->pendingRd, n);
+    return renderBatched(c, &c->pendingRd, n, true);
 }
 #define OKRT_FLUSH(c)                                \
     do {                                             \
@@ -458,15 +477,7 @@ okrt_status okrt_render_frames(okrt_ctx* c, const okrt_render_data* rd, uint32_t
     OKRT_FLUSH(c);
     if (!frames) return OKRT_OK;
     const bool batchable = c->traversal == OKRT_TRAVERSAL_FAST && rd->debugMode == 0 && rd->accumulationEnabled == 1;
-    okrt_render_data cur = *rd;
-    while (frames) {
-        const uint32_t n = batchable ? std::min<uint32_t>(frames, kMaxFramesPerLaunch) : 1u;
-        okrt_status s = renderImpl(c, &cur, n);
-        if (s != OKRT_OK) return s;
-        if (cur.accumulationEnabled == 1) cur.numAccumulationFrames += n;  // the host's pre-increment per frame (RayTracer.cpp:489)
-        frames -= n;
-    }
-    return OKRT_OK;
+    return renderBatched(c, rd, frames, batchable);
 }
 
 static okrt_status ensureTables(okrt_ctx* c) {
@@ -640,6 +651,11 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
         case OKRT_OPT_DEFER:
             if (value < 0 || value > (int64_t)kMaxFramesPerLaunch) return fail(c, OKRT_ERR_INVALID_ARG, "defer: 0 (off) .. 64 frames");
             c->deferMax = (uint32_t)value;
+            return OKRT_OK;
+        case OKRT_OPT_QUEUE_MEMORY_MB:
+            if (value < 0) return fail(c, OKRT_ERR_INVALID_ARG, "queue memory: MiB >= 0");
+            fastSetQueueBudget(&c->fast, (size_t)value << 20);
+            c->batchLimit = kMaxFramesPerLaunch;  // probe again from the top
             return OKRT_OK;
         case OKRT_OPT_BUILDER:
             if (value != 0 && value != 1) return fail(c, OKRT_ERR_INVALID_ARG, "builder: 0 (host SAH) or 1 (device PLOC)");

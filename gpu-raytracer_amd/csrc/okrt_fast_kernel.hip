@@ -756,6 +756,7 @@ struct FastScene {
     uint2* overflow = nullptr;
     uint32_t overflowCap = 0;
     int traceBlocks = 0, cus = 0;
+    size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
     float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
     size_t radianceCap = 0;
 };
@@ -810,6 +811,11 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
     return true;
 }
 
+void fastSetQueueBudget(FastScene** scene, size_t bytes) {
+    if (!*scene) *scene = new FastScene();
+    (*scene)->queueBudgetBytes = bytes;
+}
+
 void fastBuildInfo(const FastScene* fs, FastBuildInfo* info) {
     if (fs) *info = fs->info;
     else std::memset(info, 0, sizeof(*info));
@@ -859,8 +865,15 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     const uint32_t total = perFrame * frames;
     const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
     const size_t items = (size_t)cap * kShards;
+    // per item: two ray queues (16+16+16+8 B each) + hit record (16+4 B); per pixel and frame: a 16-byte radiance slot
+    const size_t needBytes = items * (2 * 56 + 20) + (frames > 1 ? (size_t)t.rows * t.W * frames * 16 : 0);
+    if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
+        err = "launch set exceeds the queue memory budget";
+        return false;
+    }
     if (items > fs.capacity) {
         hipStreamSynchronize(stream);
+        fs.capacity = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
         for (RayQueue& q : fs.q)
             if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return false;
         if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return false;
@@ -871,6 +884,7 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     if (frames > 1) {
         if (pixels * frames > fs.radianceCap) {
             hipStreamSynchronize(stream);
+            fs.radianceCap = 0;
             if (!devAlloc(&fs.radiance, pixels * frames, err)) return false;
             fs.radianceCap = pixels * frames;
         }

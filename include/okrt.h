@@ -131,14 +131,19 @@ typedef enum okrt_option {
      *     Application.cpp:312-317 on every scene edit, at interactive rates. Both cover exactly the triangles the
      *     reference shader reaches, so renders agree up to equal-distance ties. */
     OKRT_OPT_BUILDER = 4,
-    /* n >= 2 (default 16): okrt_render calls that continue the progressive accumulation of an unchanged scene (same
+    /* n >= 2 (default 32): okrt_render calls that continue the progressive accumulation of an unchanged scene (same
      * RenderData apart from numAccumulationFrames = previous + 1, fast traversal, no debug mode, library-owned stream
      * and framebuffers) are deferred and up to n of them traced by one set of kernel launches — the reference's
      * main loop `for (;;) render();` (Application.cpp:106-128) gets the throughput of okrt_render_frames without a
      * change to the host. Every other entry point (read-backs, synchronize, uploads that change a table, options,
      * timers, ...) executes the waiting frames first, so nothing can observe the deferral; the framebuffers are
      * bit-identical to immediate execution. 0 or 1 = launch every frame inside its own okrt_render. */
-    OKRT_OPT_DEFER = 5
+    OKRT_OPT_DEFER = 5,
+    /* Upper bound, in MiB, for the ray queues of one launch set (132 bytes per ray and frame in flight + 16 per
+     * pixel and frame; 1080p x 64 frames = 18 GiB). 0 (default) = whatever hipMalloc grants. A launch set that
+     * does not fit — by this bound or by the allocator — is split in halves until it does; a single frame is
+     * always attempted. */
+    OKRT_OPT_QUEUE_MEMORY_MB = 6
 } okrt_option;
 
 #define OKRT_BUILDER_HOST 0

@@ -822,6 +822,7 @@ okrt_status okrt_oracle_set_option(okrt_ctx* c, okrt_option opt, int64_t value) 
         case OKRT_OPT_TIMING: return OKRT_OK;
         case OKRT_OPT_BUILDER: return OKRT_OK;  // no derived structure here
         case OKRT_OPT_DEFER: return OKRT_OK;    // every frame is rendered inside its call
+        case OKRT_OPT_QUEUE_MEMORY_MB: return OKRT_OK;
         default: return fail(c, OKRT_ERR_INVALID_ARG, "unknown option");
     }
 }

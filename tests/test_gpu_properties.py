@@ -302,3 +302,22 @@ def test_deferred_frames_are_bit_identical_and_unobservable():
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True) if isinstance(x, np.ndarray) and x.dtype.kind == "f" else np.array_equal(x, y)
     assert a[2][..., 3].max() == 23  # alpha counts frames: nothing was lost at the end of the loop
+
+
+def test_launch_sets_shrink_to_the_queue_memory_budget():
+    """A launch set whose queues do not fit (here: an artificial 24 MiB budget; in the field: hipMalloc saying no) is
+    split in halves until it fits; the framebuffers do not change."""
+    desc = scenes.small_mesh_scene(seed=4, n_objects=5, detail=10, with_lights=True)
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.renderFrames(48)
+    want = rt.ctx.read_accum().copy()
+    rt.resetAccumulation()
+    rt.ctx.set_option(abi.OPT_QUEUE_MEMORY_MB, 24)  # 320x180 needs 7.8 MiB per frame in flight: sets of 3 at most
+    rt.renderFrames(48)
+    got = rt.ctx.read_accum()
+    assert np.array_equal(got, want, equal_nan=True)
+    rt.ctx.set_option(abi.OPT_QUEUE_MEMORY_MB, 1)  # not even one frame fits: a single frame is still attempted
+    rt.resetAccumulation()
+    rt.renderFrames(5)
+    assert np.array_equal(rt.ctx.read_accum()[..., 3], np.full((180, 320), 5.0, np.float32))
+    rt.close()
