@@ -20,8 +20,8 @@ def main(src, dst):
             k = short(r["Name"])
             out.setdefault("kernel_stats", {})[k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]),
                                                     "max_ns": int(r["MaxNs"]), "pct": float(r["Percentage"])}
-    lines.append("## rocprofv3 --kernel-trace --stats   (python3 bench.py --no-cpu-baseline --no-single-call --steps 64 --warmup 16: launch sets of 16 frames,")
-    lines.append("## so per-frame time of a kernel = max_us / 16; the two 1-frame launches of the counter pre-pass pull the averages down a little)")
+    lines.append("## rocprofv3 --kernel-trace --stats   (python3 bench.py --no-cpu-baseline --no-single-call --steps 128 --warmup 64: launch sets of 64 frames ,")
+    lines.append("## so per-frame time of a kernel = max_us / 64; the 1-frame launches of the counter pre-pass and the warm-up set pull the averages down)")
     lines.append(f"{'kernel':42s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}")
     for k, v in sorted(out.get("kernel_stats", {}).items(), key=lambda kv: -kv[1]["pct"]):
         lines.append(f"{k:42s} {v['calls']:6d} {v['avg_ns']/1e3:10.1f} {v['min_ns']/1e3:10.1f} {v['max_ns']/1e3:10.1f} {v['pct']:7.2f}")
