@@ -240,7 +240,8 @@ okrt_status okrt_set_stream(okrt_ctx* ctx, void* hip_stream);
 okrt_status okrt_timer_begin(okrt_ctx* ctx);
 okrt_status okrt_timer_end(okrt_ctx* ctx);
 okrt_status okrt_timer_elapsed_ms(okrt_ctx* ctx, float* out_ms);
-/* With OKRT_OPT_TIMING: device time of the kernels of the most recent okrt_render. */
+/* With OKRT_OPT_TIMING: device time of the kernels of the most recent launch set: one okrt_render, or the frames that
+ * were traced together (okrt_render_frames, deferred okrt_render calls). */
 okrt_status okrt_last_render_ms(okrt_ctx* ctx, float* out_ms);
 /* With OKRT_OPT_TIMING = n: device time summed over the renders still in the ring (at most n), split
  * by kernel family: out_ms[0] = traversal kernels (trace primary + queued, or the reference-order
