@@ -771,6 +771,29 @@ okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames
     return OKRT_OK;
 }
 
+okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats) {
+    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_SAMPLE_ENV) return OKRT_ERR_INVALID_ARG;
+    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3};
+    if (in_floats < needIn[op] || out_floats < needOut[op]) return fail(c, OKRT_ERR_INVALID_ARG, "kat: record too short for this probe");
+    OKRT_FLUSH(c);
+    OKRT_HIP(c, hipSetDevice(c->device));
+    if (!n) return OKRT_OK;
+    float *dIn = nullptr, *dOut = nullptr;
+    OKRT_HIP(c, hipMalloc((void**)&dIn, (size_t)n * in_floats * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&dOut, (size_t)n * out_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(dIn, in, (size_t)n * in_floats * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, (size_t)n * out_floats * sizeof(float), c->stream);
+    if (e == hipSuccess) {
+        launchKat(makeView(c), (uint32_t)op, n, dIn, in_floats, dOut, out_floats, c->stream);
+        e = hipMemcpyAsync(out, dOut, (size_t)n * out_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dIn);
+    if (dOut) hipFree(dOut);
+    if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("kat: ") + hipGetErrorString(e));
+    return OKRT_OK;
+}
+
 const okrt_api* okrt_get_api(void) {
     static const okrt_api api = {OKRT_ABI_VERSION,     okrt_create,        okrt_destroy,      okrt_last_error,
                                  okrt_set_table,       okrt_set_textures,  okrt_set_envmap,   okrt_scale_texture_rgba8,

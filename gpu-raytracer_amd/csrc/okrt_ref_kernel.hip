@@ -177,4 +177,70 @@ void launchScaleTexture(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* d
     hipLaunchKernelGGL(scaleTextureKernel, grid, dim3(256), 0, stream, src, sw, sh, dst, dw, dh);
 }
 
+// ---- known-answer probes of the device leaf functions (tests/test_gpu_kats.py) ----------------------------------------
+// One thread per record: `in` holds inFloats floats per record, `out` outFloats. Integer arguments and results travel
+// as bit patterns. The same inputs go through the CPU checker's probes of the same functions; everything here that contains no
+// transcendental must agree bit for bit.
+__global__ __launch_bounds__(256) void katKernel(SceneView s, uint32_t op, uint32_t n, const float* __restrict__ in, uint32_t inFloats,
+                                                 float* __restrict__ out, uint32_t outFloats) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + (size_t)i * inFloats;
+    float* o = out + (size_t)i * outFloats;
+    PathCounters cnt = {};
+    switch (op) {
+        case OKRT_KAT_PCG_HASH: {  // seed -> hash (== new seed)
+            uint32_t seed = __float_as_uint(a[0]);
+            o[0] = __uint_as_float(pcgHash(seed));
+            o[1] = __uint_as_float(seed);
+            break;
+        }
+        case OKRT_KAT_RANDOM_FLOAT: {
+            uint32_t seed = __float_as_uint(a[0]);
+            o[0] = randomFloat(seed);
+            o[1] = __uint_as_float(seed);
+            break;
+        }
+        case OKRT_KAT_RAY_SPHERE: {  // o[3] d[3] pos[3] radius -> t
+            Ray r;
+            r.origin = ld3(a);
+            r.direction = ld3(a + 3);
+            o[0] = rayAndSphere(r, ld3(a + 6), a[9]);
+            break;
+        }
+        case OKRT_KAT_RAY_TRIANGLE: {  // o[3] d[3] p0 p1 p2 -> t u v
+            const V3 p0 = ld3(a + 6), p1 = ld3(a + 9), p2 = ld3(a + 12);
+            float u = 0.f, v = 0.f;
+            o[0] = rayAndTriangleEdges(ld3(a), ld3(a + 3), p2, p0 - p2, p1 - p2, u, v);
+            o[1] = u;
+            o[2] = v;
+            break;
+        }
+        case OKRT_KAT_RAY_AABB: {  // o[3] d[3] min[3] max[3] -> distance
+            o[0] = rayAndAABBDist(ld3(a), rcp3(ld3(a + 3)), ld3(a + 6), ld3(a + 9));
+            break;
+        }
+        case OKRT_KAT_REFRACT: {  // d[3] n[3] ratio -> out[3]
+            const V3 r = refractUser(ld3(a), ld3(a + 3), a[6]);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case OKRT_KAT_SAMPLE_TEXTURE: {  // idx(bits) u v -> rgb
+            const V3 r = sampleTexture(s, __float_as_uint(a[0]), a[1], a[2], cnt);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case OKRT_KAT_SAMPLE_ENV: {  // d[3] -> rgb
+            const V3 r = sampleEnvironment(s, ld3(a), cnt);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        default: break;
+    }
+}
+
+void launchKat(const SceneView& s, uint32_t op, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(katKernel, dim3((n + 255) / 256), dim3(256), 0, stream, s, op, n, in, inFloats, out, outFloats);
+}
+
 }  // namespace okrt

@@ -164,6 +164,13 @@ class Context:
     def set_stream(self, stream_ptr):
         self._ck(self.fns.set_stream(self.h, stream_ptr), "set_stream")
 
+    def kat(self, op, records, out_floats):
+        """Run one device leaf function over `records` ([n, k] float32; integers as bit patterns): okrt_debug_kat."""
+        a = np.ascontiguousarray(records, dtype=np.float32)
+        out = np.zeros((a.shape[0], out_floats), np.float32)
+        self._ck(self.fns.debug_kat(self.h, op, a.shape[0], a.ctypes.data_as(P), a.shape[1], out.ctypes.data_as(P), out_floats), "debug_kat")
+        return out
+
     def commit(self):
         """Validate the tables and (re)build the traversal structure now (okrt_commit)."""
         self._ck(self.fns.commit(self.h), "commit")

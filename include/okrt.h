@@ -266,6 +266,23 @@ okrt_status okrt_get_build_info(okrt_ctx* ctx, okrt_build_info* out);
  * gpu-raytracer_amd/csrc/okrt_fast.h). Either pointer may be NULL. OKRT_ERR_STATE if nothing is built. */
 okrt_status okrt_get_fast_structure(okrt_ctx* ctx, void* nodes64, uint32_t node_capacity, void* tris48, uint32_t tri_capacity);
 
+/* Known-answer probes: runs one leaf function of the device code (gpu-raytracer_amd/csrc/okrt_device.h) over `n` records,
+ * so that tests can compare it bit for bit with the CPU oracle's restatement of the same reference function. `in`
+ * and `out` are host arrays of n * in_floats / n * out_floats floats (integers travel as bit patterns):
+ *   PCG_HASH        seed                      -> hash, new seed          (GPU-Utilities.hlsli:18-25)
+ *   RANDOM_FLOAT    seed                      -> value, new seed         (:51-54)
+ *   RAY_SPHERE      o[3] d[3] centre[3] r     -> t                       (:98-114)
+ *   RAY_TRIANGLE    o[3] d[3] p0 p1 p2        -> t, u, v                 (:117-155)
+ *   RAY_AABB        o[3] d[3] min[3] max[3]   -> distance | FLT_MAX      (:183-197)
+ *   REFRACT         d[3] n[3] ratio           -> direction[3]            (:85-93)
+ *   SAMPLE_TEXTURE  slice(bits) u v           -> rgb  (the uploaded texture array; RaytracerCS.hlsl:133-136)
+ *   SAMPLE_ENV      d[3]                      -> rgb  (the uploaded cube map; :86-88) */
+typedef enum okrt_kat {
+    OKRT_KAT_PCG_HASH = 0, OKRT_KAT_RANDOM_FLOAT = 1, OKRT_KAT_RAY_SPHERE = 2, OKRT_KAT_RAY_TRIANGLE = 3, OKRT_KAT_RAY_AABB = 4,
+    OKRT_KAT_REFRACT = 5, OKRT_KAT_SAMPLE_TEXTURE = 6, OKRT_KAT_SAMPLE_ENV = 7
+} okrt_kat;
+okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats);
+
 /* ---- entry-point table -------------------------------------------------------------------------
  * The same entry points as a struct of function pointers, so a host written against this ABI
  * (gpu-raytracer_amd/host: the mirror of the reference's RayTracer class) binds to the device

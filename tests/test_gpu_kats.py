@@ -1,0 +1,177 @@
+"""The device's leaf functions against the oracle's, bit for bit, on thousands of random and adversarial inputs
+(okrt_debug_kat runs csrc/okrt_device.h's functions on the GPU; okrt_oracle_kat_* are the CPU restatement that
+test_oracle_kats.py pins to the shader text). Everything that contains no transcendental — RNG, the three
+intersection routines, the user refract, both texture samplers — must be IDENTICAL: the render-level tolerances of
+test_gpu_parity.py are then left to cover sin/cos/log/exp2/log2/atan2 only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import abi, host
+
+pytestmark = pytest.mark.gpu
+F3 = C.c_float * 3
+N = 4000
+
+
+def bits(u):
+    return np.asarray(u, np.uint32).view(np.float32)
+
+
+def same_bits(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32)) or np.array_equal(a, b, equal_nan=True) and \
+        np.array_equal(np.isnan(a), np.isnan(b))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    ctx = host.Context()
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def lib(oracle):
+    l = oracle.lib
+    l.okrt_oracle_kat_pcg_hash.restype = C.c_uint32
+    l.okrt_oracle_kat_random_float.restype = C.c_float
+    for n in ("ray_sphere", "ray_triangle", "ray_aabb"):
+        getattr(l, "okrt_oracle_kat_" + n).restype = C.c_float
+    l.okrt_oracle_kat_ray_sphere.argtypes = [F3, F3, F3, C.c_float]
+    l.okrt_oracle_kat_ray_triangle.argtypes = [F3, F3, C.c_float * 9, C.c_float * 2]
+    l.okrt_oracle_kat_ray_aabb.argtypes = [F3, F3, F3, F3]
+    l.okrt_oracle_kat_refract.argtypes = [F3, F3, C.c_float, F3]
+    l.okrt_oracle_kat_sample_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, F3]
+    l.okrt_oracle_kat_sample_env.argtypes = [C.c_void_p, F3, F3]
+    return l
+
+
+def test_rng(gpu, lib):
+    rng = np.random.default_rng(1)
+    seeds = np.concatenate([[0, 1, 2, 0xFFFFFFFF, 74813, 1920 * 74813 * 2], rng.integers(0, 2**32, N)]).astype(np.uint32)
+    got = gpu.kat(abi.KAT_PCG_HASH, bits(seeds)[:, None], 2).view(np.uint32)
+    gotf = gpu.kat(abi.KAT_RANDOM_FLOAT, bits(seeds)[:, None], 2)
+    for i, s in enumerate(seeds):
+        c = C.c_uint32(int(s))
+        assert lib.okrt_oracle_kat_pcg_hash(C.byref(c)) == got[i, 0] == got[i, 1] == c.value
+        c = C.c_uint32(int(s))
+        want = lib.okrt_oracle_kat_random_float(C.byref(c))
+        assert np.float32(want) == gotf[i, 0] and c.value == gotf[i, 1:].view(np.uint32)[0]
+
+
+def rays(rng, n, spread=10.0):
+    o = rng.normal(0, spread, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d[: n // 8] = np.sign(d[: n // 8])                        # axis-diagonal directions
+    d[n // 8: n // 4, rng.integers(0, 3)] = 0.0               # a zero component: 1/0 = inf in the slab test
+    return o, d
+
+
+def test_ray_sphere(gpu, lib):
+    rng = np.random.default_rng(2)
+    o, d = rays(rng, N)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    pos = rng.normal(0, 10, (N, 3)).astype(np.float32)
+    rad = rng.uniform(0.1, 12, N).astype(np.float32)
+    pos[:50] = o[:50]                                         # origin at the centre
+    aim = slice(1000, 3000)                                   # half of the rays are aimed near their sphere
+    t = pos[aim] + rng.normal(0, 0.6, (2000, 3)).astype(np.float32) * rad[aim, None] - o[aim]
+    d[aim] = (t / np.linalg.norm(t, axis=1, keepdims=True)).astype(np.float32)
+    got = gpu.kat(abi.KAT_RAY_SPHERE, np.concatenate([o, d, pos, rad[:, None]], 1), 1)[:, 0]
+    want = np.array([lib.okrt_oracle_kat_ray_sphere(F3(*o[i]), F3(*d[i]), F3(*pos[i]), float(rad[i])) for i in range(N)], np.float32)
+    assert same_bits(got, want)
+    assert (got > 0).mean() > 0.2 and (got == -1).mean() > 0.2
+
+
+def test_ray_triangle(gpu, lib):
+    rng = np.random.default_rng(3)
+    o, d = rays(rng, N, 4.0)
+    tri = rng.normal(0, 4, (N, 9)).astype(np.float32)
+    tri[:40, 3:6] = tri[:40, 0:3]                             # degenerate: two equal vertices
+    d[40:80] = (tri[40:80, 3:6] - tri[40:80, 0:3])           # ray parallel to an edge
+    o[80:400] = (tri[80:400, 0:3] + tri[80:400, 3:6] + tri[80:400, 6:9]) / 3 - d[80:400] * 2  # aimed at the centroid
+    o[400:500] = tri[400:500, 0:3] - d[400:500]               # aimed exactly at a vertex
+    got = gpu.kat(abi.KAT_RAY_TRIANGLE, np.concatenate([o, d, tri], 1), 3)
+    want = np.zeros((N, 3), np.float32)
+    for i in range(N):
+        uv = (C.c_float * 2)()
+        want[i, 0] = lib.okrt_oracle_kat_ray_triangle(F3(*o[i]), F3(*d[i]), (C.c_float * 9)(*tri[i]), uv)
+        want[i, 1:] = uv[0], uv[1]
+    hit = want[:, 0] > 0
+    assert same_bits(got[:, 0], want[:, 0])
+    assert same_bits(got[hit, 1:], want[hit, 1:])             # barycentrics are only defined on a hit
+    assert hit.sum() > 300
+
+
+def test_ray_aabb(gpu, lib):
+    rng = np.random.default_rng(4)
+    o, d = rays(rng, N)
+    a, b = rng.normal(0, 8, (N, 3)).astype(np.float32), rng.normal(0, 8, (N, 3)).astype(np.float32)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    o[:200] = ((lo[:200] + hi[:200]) / 2).astype(np.float32)  # origin inside: negative entry distance
+    lo[200:260, 1] = hi[200:260, 1]                           # flat box
+    aim = slice(1000, 3000)                                   # half of the rays are aimed into their box
+    d[aim] = (lo[aim] + (hi[aim] - lo[aim]) * rng.uniform(0, 1, (2000, 3)).astype(np.float32)) - o[aim]
+    got = gpu.kat(abi.KAT_RAY_AABB, np.concatenate([o, d, lo, hi], 1), 1)[:, 0]
+    want = np.array([lib.okrt_oracle_kat_ray_aabb(F3(*o[i]), F3(*d[i]), F3(*lo[i]), F3(*hi[i])) for i in range(N)], np.float32)
+    assert same_bits(got, want)
+    assert (got < 3e38).mean() > 0.2
+
+
+def test_user_refract(gpu, lib):
+    rng = np.random.default_rng(5)
+    d = rng.normal(0, 1, (N, 3)).astype(np.float32)
+    n = rng.normal(0, 1, (N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True).astype(np.float32)
+    ratio = rng.choice(np.array([1 / 1.5, 1.5, 1.0, 1 / 1.33, 2.4], np.float32), N)
+    got = gpu.kat(abi.KAT_REFRACT, np.concatenate([d, n, ratio[:, None]], 1), 3)
+    want = np.zeros((N, 3), np.float32)
+    for i in range(N):
+        out = F3()
+        lib.okrt_oracle_kat_refract(F3(*d[i]), F3(*n[i]), float(ratio[i]), out)
+        want[i] = out[0], out[1], out[2]
+    assert same_bits(got, want)
+
+
+@pytest.mark.parametrize("side", [64, 48])  # power of two (exact reciprocal path) and not
+def test_texture_sampler(gpu, oracle, lib, side):
+    rng = np.random.default_rng(6)
+    tex = rng.integers(0, 256, (3, side, side, 4), dtype=np.uint8)
+    octx = oracle.context()
+    octx.set_textures(tex)
+    gpu.set_textures(tex)
+    idx = rng.integers(0, 5, N).astype(np.uint32)             # beyond the array: clamps
+    uv = rng.uniform(-3, 3, (N, 2)).astype(np.float32)
+    uv[:100] = np.round(uv[:100] * side) / side               # exactly on texel edges
+    uv[100:140] = [[0.0, 0.0]]
+    uv[140:150] = [[np.inf, np.nan]]                          # non-finite coordinates are zeroed
+    got = gpu.kat(abi.KAT_SAMPLE_TEXTURE, np.concatenate([bits(idx)[:, None], uv], 1), 3)
+    want = np.zeros((N, 3), np.float32)
+    for i in range(N):
+        out = F3()
+        lib.okrt_oracle_kat_sample_texture(octx.h, int(idx[i]), float(uv[i, 0]), float(uv[i, 1]), out)
+        want[i] = out[0], out[1], out[2]
+    octx.close()
+    assert same_bits(got, want)
+
+
+def test_environment_sampler(gpu, oracle, lib):
+    rng = np.random.default_rng(7)
+    faces = rng.integers(0, 256, (6, 32, 32, 4), dtype=np.uint8)
+    octx = oracle.context()
+    octx.set_envmap(faces)
+    gpu.set_envmap(faces)
+    d = rng.normal(0, 1, (N, 3)).astype(np.float32)
+    d[:60] = np.sign(d[:60])                                  # cube corners / edges: face selection ties
+    d[60:70] = 0.0
+    got = gpu.kat(abi.KAT_SAMPLE_ENV, d, 3)
+    want = np.zeros((N, 3), np.float32)
+    for i in range(N):
+        out = F3()
+        lib.okrt_oracle_kat_sample_env(octx.h, F3(*d[i]), out)
+        want[i] = out[0], out[1], out[2]
+    octx.close()
+    assert same_bits(got, want)
