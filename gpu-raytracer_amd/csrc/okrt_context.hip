@@ -772,11 +772,16 @@ okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames
 }
 
 okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats) {
-    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_SAMPLE_ENV) return OKRT_ERR_INVALID_ARG;
-    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3};
+    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_CLOSEST_HIT_FAST) return OKRT_ERR_INVALID_ARG;
+    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5};
     if (in_floats < needIn[op] || out_floats < needOut[op]) return fail(c, OKRT_ERR_INVALID_ARG, "kat: record too short for this probe");
     OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
+    if (op == OKRT_KAT_CLOSEST_HIT || op == OKRT_KAT_CLOSEST_HIT_FAST) {  // walks the uploaded tables: they must be consistent
+        okrt_status vs = ensureTables(c);
+        if (vs == OKRT_OK && op == OKRT_KAT_CLOSEST_HIT_FAST) vs = ensureFast(c);
+        if (vs != OKRT_OK) return vs;
+    }
     if (!n) return OKRT_OK;
     float *dIn = nullptr, *dOut = nullptr;
     OKRT_HIP(c, hipMalloc((void**)&dIn, (size_t)n * in_floats * sizeof(float)));
@@ -784,7 +789,16 @@ okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in
     if (e == hipSuccess) e = hipMemcpyAsync(dIn, in, (size_t)n * in_floats * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, (size_t)n * out_floats * sizeof(float), c->stream);
     if (e == hipSuccess) {
-        launchKat(makeView(c), (uint32_t)op, n, dIn, in_floats, dOut, out_floats, c->stream);
+        std::string msg;
+        if (op == OKRT_KAT_CLOSEST_HIT_FAST) {
+            if (!fastKat(c->fast, makeView(c), n, dIn, in_floats, dOut, out_floats, c->stream, msg)) {
+                hipFree(dIn);
+                hipFree(dOut);
+                return fail(c, OKRT_ERR_STATE, "kat: " + msg);
+            }
+        } else {
+            launchKat(makeView(c), (uint32_t)op, n, dIn, in_floats, dOut, out_floats, c->stream);
+        }
         e = hipMemcpyAsync(out, dOut, (size_t)n * out_floats * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

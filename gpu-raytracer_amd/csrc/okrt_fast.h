@@ -110,6 +110,9 @@ struct FastBuildInfo { uint32_t builder, numNodes, numTris, maxDepth; float devi
 // builder: 0 = host binned SAH (okrt_fast_build.cpp), 1 = device PLOC (okrt_fast_build_device.hip)
 bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& dev, uint32_t builder, hipStream_t stream, std::string& err);
 void fastBuildInfo(const FastScene* scene, FastBuildInfo* info);
+// known-answer probe: closest hit of n rays through the structure, one thread per ray (okrt_debug_kat)
+bool fastKat(const FastScene* scene, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats,
+             hipStream_t stream, std::string& err);
 // upper bound for the wavefront queues of one launch set (0 = none): larger sets are refused and the caller halves them
 void fastSetQueueBudget(FastScene** scene, size_t bytes);
 // copies the structure back to the host (tests); either pointer may be null

@@ -811,6 +811,94 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
     return true;
 }
 
+// Known-answer probe (okrt_debug_kat, CLOSEST_HIT_FAST): one thread per ray walks the structure with a private stack —
+// the same node decoding, slab arithmetic, triangle test and hit-distance formula as the trace kernels, none of their
+// scheduling — so tests can compare the structure's closest hit with the oracle's ray by ray.
+__global__ __launch_bounds__(64) void fastKatKernel(const uint4* __restrict__ nodes, const float4* __restrict__ tris, SceneView s, uint32_t n,
+                                                    const float* __restrict__ in, uint32_t inFloats, float* __restrict__ out, uint32_t outFloats) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + (size_t)i * inFloats;
+    float* o = out + (size_t)i * outFloats;
+    Ray ray;
+    ray.origin = ld3(a);
+    ray.direction = ld3(a + 3);
+    const uint32_t numSpheres = __float_as_uint(a[6]);
+    float best = kFltMax;
+    uint32_t hitIdx = kInvalid, hitTri = kInvalid;
+    for (uint32_t k = 0; k < numSpheres; k++) {
+        const float d = rayAndSphere(ray, ld3(s.spheres[k].position), s.spheres[k].radius);
+        if (d > 0.f && d < best) {
+            best = d;
+            hitIdx = k;
+        }
+    }
+    const V3 ro = ray.origin, rdir = normalize(ray.direction);
+    V3 iq = rcp3(rdir);
+    iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
+    uint32_t stack[256];
+    uint32_t sp = 0, visited = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const uint32_t cur = stack[--sp];
+        if (cur == kEmptyRef) continue;
+        if (cur & kLeafBit) {
+            const uint32_t count = ((cur >> 27) & 15u) + 1u;
+            const float4* tp = tris + (size_t)(cur & 0x07FFFFFFu) * 3;
+            for (uint32_t j = 0; j < count; ++j, tp += 3) {
+                const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                float bu = 0.f, bv = 0.f;
+                const float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
+                if (t > 0.f) {
+                    const float d = length(rdir * t);
+                    if (d < best) {
+                        best = d;
+                        hitTri = __float_as_uint(t0.w);
+                        hitIdx = __float_as_uint(t1.w);
+                    }
+                }
+            }
+            continue;
+        }
+        ++visited;
+        const uint4* np = nodes + (size_t)cur * 4;
+        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        const uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
+        const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
+        const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
+        const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
+        const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
+        const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
+        const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
+        for (int k = 0; k < 4; ++k) {
+            const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
+                                      fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
+            const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
+                                     fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
+            if (tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef && sp < 256u) stack[sp++] = ch[k];
+        }
+    }
+    o[0] = best;
+    o[1] = __uint_as_float(hitIdx != kInvalid ? 1u : 0u);
+    o[2] = __uint_as_float(visited);
+    o[3] = __uint_as_float(hitIdx);
+    o[4] = __uint_as_float(hitTri);
+}
+
+bool fastKat(const FastScene* fs, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, hipStream_t stream,
+             std::string& err) {
+    if (!fs || !fs->nodes.p) {
+        err = "no structure built yet";
+        return false;
+    }
+    if (4 * fs->maxDepth + 4 > 256u) {
+        err = "tree too deep for the probe's private stack";
+        return false;
+    }
+    if (n) hipLaunchKernelGGL(fastKatKernel, dim3((n + 63) / 64), dim3(64), 0, stream, fs->nodes.p, fs->tris.p, s, n, in, inFloats, out, outFloats);
+    return true;
+}
+
 void fastSetQueueBudget(FastScene** scene, size_t bytes) {
     if (!*scene) *scene = new FastScene();
     (*scene)->queueBudgetBytes = bytes;

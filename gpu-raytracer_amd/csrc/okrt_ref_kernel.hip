@@ -235,6 +235,22 @@ __global__ __launch_bounds__(256) void katKernel(SceneView s, uint32_t op, uint3
             o[0] = r.x; o[1] = r.y; o[2] = r.z;
             break;
         }
+        case OKRT_KAT_CLOSEST_HIT: {  // o[3] d[3] numSpheres(bits) -> distance, hit?, bbCheckCount, triCheckCount, hitIdx, triIdx
+            okrt_render_data rd = {};
+            rd.numSpheres = __float_as_uint(a[6]);
+            Ray r;
+            r.origin = ld3(a);
+            r.direction = ld3(a + 3);
+            uint32_t bb = 0, tri = 0;
+            const Hit h = closestHitReferenceOrder(s, rd, r, bb, tri, cnt);
+            o[0] = h.distance;
+            o[1] = __uint_as_float(h.hitIdx != kInvalid ? 1u : 0u);
+            o[2] = __uint_as_float(bb);
+            o[3] = __uint_as_float(tri);
+            o[4] = __uint_as_float(h.hitIdx);
+            o[5] = __uint_as_float(h.triIdx);
+            break;
+        }
         default: break;
     }
 }

@@ -276,10 +276,15 @@ okrt_status okrt_get_fast_structure(okrt_ctx* ctx, void* nodes64, uint32_t node_
  *   RAY_AABB        o[3] d[3] min[3] max[3]   -> distance | FLT_MAX      (:183-197)
  *   REFRACT         d[3] n[3] ratio           -> direction[3]            (:85-93)
  *   SAMPLE_TEXTURE  slice(bits) u v           -> rgb  (the uploaded texture array; RaytracerCS.hlsl:133-136)
- *   SAMPLE_ENV      d[3]                      -> rgb  (the uploaded cube map; :86-88) */
+ *   SAMPLE_ENV      d[3]                      -> rgb  (the uploaded cube map; :86-88)
+ *   CLOSEST_HIT     o[3] d[3] numSpheres(bits) -> distance, hit?, bbCheckCount, triCheckCount, hitIdx, triIdx
+ *                   (the reference-order traversal over the uploaded tables; RaytracerCS.hlsl:218-334)
+ *   CLOSEST_HIT_FAST o[3] d[3] numSpheres(bits) -> distance, hit?, nodes visited, hitIdx, triIdx
+ *                   (the derived traversal structure, walked by one thread per ray) */
 typedef enum okrt_kat {
     OKRT_KAT_PCG_HASH = 0, OKRT_KAT_RANDOM_FLOAT = 1, OKRT_KAT_RAY_SPHERE = 2, OKRT_KAT_RAY_TRIANGLE = 3, OKRT_KAT_RAY_AABB = 4,
-    OKRT_KAT_REFRACT = 5, OKRT_KAT_SAMPLE_TEXTURE = 6, OKRT_KAT_SAMPLE_ENV = 7
+    OKRT_KAT_REFRACT = 5, OKRT_KAT_SAMPLE_TEXTURE = 6, OKRT_KAT_SAMPLE_ENV = 7, OKRT_KAT_CLOSEST_HIT = 8,
+    OKRT_KAT_CLOSEST_HIT_FAST = 9
 } okrt_kat;
 okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats);
 
