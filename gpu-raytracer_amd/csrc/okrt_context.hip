@@ -772,8 +772,8 @@ okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames
 }
 
 okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats) {
-    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_CLOSEST_HIT_FAST) return OKRT_ERR_INVALID_ARG;
-    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5};
+    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_PRIMARY_RAY) return OKRT_ERR_INVALID_ARG;
+    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7, 1, 2, 8, 8, 62}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5, 4, 1, 4, 4, 7};
     if (in_floats < needIn[op] || out_floats < needOut[op]) return fail(c, OKRT_ERR_INVALID_ARG, "kat: record too short for this probe");
     OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));

@@ -235,6 +235,42 @@ __global__ __launch_bounds__(256) void katKernel(SceneView s, uint32_t op, uint3
             o[0] = r.x; o[1] = r.y; o[2] = r.z;
             break;
         }
+        case OKRT_KAT_RANDOM_VECTOR: {  // seed -> v[3], new seed   (Box-Muller: log, cos)
+            uint32_t seed = __float_as_uint(a[0]);
+            const V3 r = randomVector(seed);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            o[3] = __uint_as_float(seed);
+            break;
+        }
+        case OKRT_KAT_REFLECTANCE: {  // cosine, index -> Schlick with (1 + r0) (quirk Q5; pow = exp2(y log2 x))
+            o[0] = reflectance(a[0], a[1]);
+            break;
+        }
+        case OKRT_KAT_REFLECT_DIRECTION: {  // d[3] n[3] roughness seed -> out[3], new seed
+            uint32_t seed = __float_as_uint(a[7]);
+            const V3 r = findReflectDirection(ld3(a), ld3(a + 3), a[6], seed);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            o[3] = __uint_as_float(seed);
+            break;
+        }
+        case OKRT_KAT_TRANSPARENCY_BOUNCE: {  // d[3] n[3] ior seed -> out[3], new seed   (quirks Q6-Q8)
+            uint32_t seed = __float_as_uint(a[7]);
+            const V3 r = findTransparencyBounce(ld3(a), ld3(a + 3), a[6], seed);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            o[3] = __uint_as_float(seed);
+            break;
+        }
+        case OKRT_KAT_PRIMARY_RAY: {  // px(bits) py(bits) RenderData[60] -> origin[3], direction[3], seed after createRay + applyDOF
+            okrt_render_data rd;
+            float* rf = reinterpret_cast<float*>(&rd);
+            for (int k = 0; k < 60; ++k) rf[k] = a[2 + k];
+            uint32_t seed = 0;
+            const Ray r = primaryRay(rd, __float_as_uint(a[0]), __float_as_uint(a[1]), seed);
+            o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z;
+            o[3] = r.direction.x; o[4] = r.direction.y; o[5] = r.direction.z;
+            o[6] = __uint_as_float(seed);
+            break;
+        }
         case OKRT_KAT_CLOSEST_HIT: {  // o[3] d[3] numSpheres(bits) -> distance, hit?, bbCheckCount, triCheckCount, hitIdx, triIdx
             okrt_render_data rd = {};
             rd.numSpheres = __float_as_uint(a[6]);

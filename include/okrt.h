@@ -280,11 +280,18 @@ okrt_status okrt_get_fast_structure(okrt_ctx* ctx, void* nodes64, uint32_t node_
  *   CLOSEST_HIT     o[3] d[3] numSpheres(bits) -> distance, hit?, bbCheckCount, triCheckCount, hitIdx, triIdx
  *                   (the reference-order traversal over the uploaded tables; RaytracerCS.hlsl:218-334)
  *   CLOSEST_HIT_FAST o[3] d[3] numSpheres(bits) -> distance, hit?, nodes visited, hitIdx, triIdx
- *                   (the derived traversal structure, walked by one thread per ray) */
+ *                   (the derived traversal structure, walked by one thread per ray)
+ * and, containing transcendentals (device libm vs host libm: last-ulp agreement only):
+ *   RANDOM_VECTOR   seed                      -> v[3], new seed          (GPU-Utilities.hlsli:56-70)
+ *   REFLECTANCE     cosine, index             -> value                   (RaytracerCS.hlsl:100-105)
+ *   REFLECT_DIRECTION    d[3] n[3] roughness seed -> direction[3], new seed   (:107-112)
+ *   TRANSPARENCY_BOUNCE  d[3] n[3] ior seed       -> direction[3], new seed   (:114-131)
+ *   PRIMARY_RAY     px(bits) py(bits) RenderData[60 floats] -> origin[3], direction[3], seed   (:177-216, 430) */
 typedef enum okrt_kat {
     OKRT_KAT_PCG_HASH = 0, OKRT_KAT_RANDOM_FLOAT = 1, OKRT_KAT_RAY_SPHERE = 2, OKRT_KAT_RAY_TRIANGLE = 3, OKRT_KAT_RAY_AABB = 4,
     OKRT_KAT_REFRACT = 5, OKRT_KAT_SAMPLE_TEXTURE = 6, OKRT_KAT_SAMPLE_ENV = 7, OKRT_KAT_CLOSEST_HIT = 8,
-    OKRT_KAT_CLOSEST_HIT_FAST = 9
+    OKRT_KAT_CLOSEST_HIT_FAST = 9, OKRT_KAT_RANDOM_VECTOR = 10, OKRT_KAT_REFLECTANCE = 11, OKRT_KAT_REFLECT_DIRECTION = 12,
+    OKRT_KAT_TRANSPARENCY_BOUNCE = 13, OKRT_KAT_PRIMARY_RAY = 14
 } okrt_kat;
 okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats);
 

@@ -217,3 +217,72 @@ def test_reference_order_closest_hit(oracle, lib):
         assert fi[:, 2].mean() < gi[:, 2].mean()  # 4-wide node visits vs the reference's box checks, even unordered
     rt.close()
     ort.close()
+
+
+# ---- functions with transcendentals: device libm (ocml) vs glibc agree to the last ulp or two, not to the bit ---------
+def close(a, b, rel=4e-6, abs_=4e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    ok = np.isclose(a, b, rtol=rel, atol=abs_) | (np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b)))
+    return ok
+
+
+def test_random_vector_reflectance_and_bsdf_directions(gpu, lib):
+    rng = np.random.default_rng(9)
+    n = 2000
+    lib.okrt_oracle_kat_random_vector.argtypes = [C.POINTER(C.c_uint32), F3]
+    lib.okrt_oracle_kat_reflectance.argtypes = [C.c_float, C.c_float]
+    lib.okrt_oracle_kat_reflectance.restype = C.c_float
+    lib.okrt_oracle_kat_reflect_direction.argtypes = [F3, F3, C.c_float, C.POINTER(C.c_uint32), F3]
+    lib.okrt_oracle_kat_transparency_bounce.argtypes = [F3, F3, C.c_float, C.POINTER(C.c_uint32), F3]
+    seeds = rng.integers(1, 2**32, n).astype(np.uint32)
+    got = gpu.kat(abi.KAT_RANDOM_VECTOR, bits(seeds)[:, None], 4)
+    for i in range(n):
+        s, out = C.c_uint32(int(seeds[i])), F3()
+        lib.okrt_oracle_kat_random_vector(C.byref(s), out)
+        assert close(got[i, :3], [out[0], out[1], out[2]]).all(), (i, got[i], list(out))
+        assert s.value == got[i, 3:].view(np.uint32)[0]  # six draws consumed on both sides
+    cosv = rng.uniform(0, 1, n).astype(np.float32)
+    idx = rng.choice(np.array([1 / 1.5, 1.5, 1.0, 1.33, 2.4], np.float32), n)
+    got = gpu.kat(abi.KAT_REFLECTANCE, np.stack([cosv, idx], 1), 1)[:, 0]
+    want = [lib.okrt_oracle_kat_reflectance(float(cosv[i]), float(idx[i])) for i in range(n)]
+    assert close(got, want).all()
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    nn = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True).astype(np.float32)
+    rough = rng.uniform(0, 1, n).astype(np.float32)
+    ior = rng.choice(np.array([1.5, 1.33, 1.0, 2.4], np.float32), n)
+    g1 = gpu.kat(abi.KAT_REFLECT_DIRECTION, np.concatenate([d, nn, rough[:, None], bits(seeds)[:, None]], 1), 4)
+    g2 = gpu.kat(abi.KAT_TRANSPARENCY_BOUNCE, np.concatenate([d, nn, ior[:, None], bits(seeds)[:, None]], 1), 4)
+    flips = 0
+    for i in range(n):
+        s, out = C.c_uint32(int(seeds[i])), F3()
+        lib.okrt_oracle_kat_reflect_direction(F3(*d[i]), F3(*nn[i]), float(rough[i]), C.byref(s), out)
+        assert close(g1[i, :3], [out[0], out[1], out[2]], 2e-5, 2e-5).all() and s.value == g1[i, 3:].view(np.uint32)[0], i
+        s = C.c_uint32(int(seeds[i]))
+        lib.okrt_oracle_kat_transparency_bounce(F3(*d[i]), F3(*nn[i]), float(ior[i]), C.byref(s), out)
+        assert s.value == g2[i, 3:].view(np.uint32)[0]      # the Fresnel draw is always consumed (Q6)
+        flips += not close(g2[i, :3], [out[0], out[1], out[2]], 2e-5, 2e-5).all()  # refl > rnd can flip on a last-ulp pow
+    assert flips <= 2, flips
+
+
+def test_primary_ray(gpu, oracle, lib):
+    desc = scenes.small_mesh_scene(seed=3)
+    ort, _, _ = oracle.instantiate(desc, 640, 360)
+    ort.setDOF(0.7, 9.0)
+    ort.updateBuffers()
+    rd = ort.render_data
+    lib.okrt_oracle_kat_primary_ray.argtypes = [C.POINTER(type(rd)), C.c_uint32, C.c_uint32, F3, F3, C.POINTER(C.c_uint32)]
+    rdf = np.frombuffer(bytes(rd), np.float32)
+    assert rdf.size == 60
+    rng = np.random.default_rng(10)
+    n = 2000
+    px, py = rng.integers(0, 640, n).astype(np.uint32), rng.integers(0, 360, n).astype(np.uint32)
+    rec = np.concatenate([bits(px)[:, None], bits(py)[:, None], np.broadcast_to(rdf, (n, 60))], 1)
+    got = gpu.kat(abi.KAT_PRIMARY_RAY, rec, 7)
+    for i in range(n):
+        o, d, s = F3(), F3(), C.c_uint32(0)
+        lib.okrt_oracle_kat_primary_ray(C.byref(rd), int(px[i]), int(py[i]), o, d, C.byref(s))
+        assert s.value == got[i, 6:].view(np.uint32)[0]
+        assert close(got[i, :3], list(o), 1e-5, 1e-5).all() and close(got[i, 3:6], list(d), 1e-5, 1e-5).all(), i
+    ort.close()
