@@ -327,6 +327,25 @@ okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint3
     return OKRT_OK;
 }
 
+// Row-major RGBA8 slices from the caller -> 4x4-texel tiles in `dst` (okrt_device.h: tiledOffset). The caller's buffer
+// is copied by the time this returns.
+static okrt_status uploadTiled(okrt_ctx* c, DeviceBuffer& dst, const uint8_t* rgba8, uint32_t slices, uint32_t width, uint32_t height) {
+    const size_t linear = (size_t)slices * width * height * 4;
+    const size_t tiled = (size_t)slices * ((width + 3) / 4) * ((height + 3) / 4) * 64;
+    okrt_status s = ensure(c, dst, tiled);
+    if (s != OKRT_OK) return s;
+    void* staging = nullptr;
+    OKRT_HIP(c, hipMalloc(&staging, linear));
+    hipError_t e = hipMemcpyAsync(staging, rgba8, linear, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launchTileTextures(staging, dst.ptr, slices, width, height, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(staging);
+    if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("texture upload: ") + hipGetErrorString(e));
+    return OKRT_OK;
+}
+
 okrt_status okrt_set_textures(okrt_ctx* c, const uint8_t* rgba8, uint32_t count, uint32_t width, uint32_t height) {
     if (!c) return OKRT_ERR_INVALID_ARG;
     OKRT_FLUSH(c);
@@ -336,11 +355,8 @@ okrt_status okrt_set_textures(okrt_ctx* c, const uint8_t* rgba8, uint32_t count,
         c->numTextures = c->texW = c->texH = 0;
         return s;
     }
-    size_t bytes = (size_t)count * width * height * 4;
-    okrt_status s = ensure(c, c->textures, bytes);
+    okrt_status s = uploadTiled(c, c->textures, rgba8, count, width, height);
     if (s != OKRT_OK) return s;
-    OKRT_HIP(c, hipMemcpyAsync(c->textures.ptr, rgba8, bytes, hipMemcpyHostToDevice, c->stream));
-    OKRT_HIP(c, hipStreamSynchronize(c->stream));  // the caller's buffer is copied by the time we return
     c->numTextures = count;
     c->texW = width;
     c->texH = height;
@@ -356,11 +372,8 @@ okrt_status okrt_set_envmap(okrt_ctx* c, const uint8_t* faces, uint32_t face) {
         c->envFace = 0;
         return s;
     }
-    size_t bytes = (size_t)6 * face * face * 4;
-    okrt_status s = ensure(c, c->env, bytes);
+    okrt_status s = uploadTiled(c, c->env, faces, 6, face, face);
     if (s != OKRT_OK) return s;
-    OKRT_HIP(c, hipMemcpyAsync(c->env.ptr, faces, bytes, hipMemcpyHostToDevice, c->stream));
-    OKRT_HIP(c, hipStreamSynchronize(c->stream));
     c->envFace = face;
     return OKRT_OK;
 }

@@ -220,6 +220,13 @@ OKRT_DEV int wrapIndex(float w, int n) {
     }
     return i;
 }
+// Texture memory is tiled: 4x4 texels = 64 bytes = one HBM access granule, tiles row-major, edge tiles padded. The
+// 2x2 footprint of a bilinear tap falls into one tile in 9 of 16 cases and into two in 6 more; in the row-major
+// layout the uploads arrive in it always spans two lines (okrt_set_textures / okrt_set_envmap re-tile on upload).
+OKRT_DEV uint32_t tilesAcross(int n) { return ((uint32_t)n + 3u) >> 2; }
+OKRT_DEV size_t tiledOffset(int x, int y, uint32_t tilesX) {
+    return ((size_t)((uint32_t)y >> 2) * tilesX + ((uint32_t)x >> 2)) * 64 + (((uint32_t)y & 3u) * 4u + ((uint32_t)x & 3u)) * 4u;
+}
 OKRT_DEV V3 bilerp(V3 t00, V3 t10, V3 t01, V3 t11, float fx, float fy) {
     return lerp(lerp(t00, t10, fx), lerp(t01, t11, fx), fy);
 }
@@ -238,9 +245,10 @@ OKRT_DEV V3 sampleTexture(const SceneView& s, uint32_t textureIdx, float u, floa
     int x0 = wrapIndex(wx, W), y0 = wrapIndex(wy, H);
     int x1 = x0 + 1 == W ? 0 : x0 + 1;
     int y1 = y0 + 1 == H ? 0 : y0 + 1;
-    const uint8_t* base = s.textures + (size_t)slice * W * H * 4;
-    V3 t00 = texel(base + ((size_t)y0 * W + x0) * 4), t10 = texel(base + ((size_t)y0 * W + x1) * 4);
-    V3 t01 = texel(base + ((size_t)y1 * W + x0) * 4), t11 = texel(base + ((size_t)y1 * W + x1) * 4);
+    const uint32_t tx = tilesAcross(W);
+    const uint8_t* base = s.textures + (size_t)slice * tx * tilesAcross(H) * 64;
+    V3 t00 = texel(base + tiledOffset(x0, y0, tx)), t10 = texel(base + tiledOffset(x1, y0, tx));
+    V3 t01 = texel(base + tiledOffset(x0, y1, tx)), t11 = texel(base + tiledOffset(x1, y1, tx));
     return bilerp(t00, t10, t01, t11, fx, fy);
 }
 OKRT_DEV V3 sampleEnvironment(const SceneView& s, V3 d, PathCounters& cnt) {  // RaytracerCS.hlsl:86-88
@@ -268,9 +276,10 @@ OKRT_DEV V3 sampleEnvironment(const SceneView& s, V3 d, PathCounters& cnt) {  //
     float fx = x - fx0, fy = y - fy0;
     int x0 = min(max((int)fx0, 0), F - 1), x1 = min(max((int)fx0 + 1, 0), F - 1);
     int y0 = min(max((int)fy0, 0), F - 1), y1 = min(max((int)fy0 + 1, 0), F - 1);
-    const uint8_t* base = s.env + (size_t)face * F * F * 4;
-    V3 t00 = texel(base + ((size_t)y0 * F + x0) * 4), t10 = texel(base + ((size_t)y0 * F + x1) * 4);
-    V3 t01 = texel(base + ((size_t)y1 * F + x0) * 4), t11 = texel(base + ((size_t)y1 * F + x1) * 4);
+    const uint32_t tx = tilesAcross(F);
+    const uint8_t* base = s.env + (size_t)face * tx * tx * 64;
+    V3 t00 = texel(base + tiledOffset(x0, y0, tx)), t10 = texel(base + tiledOffset(x1, y0, tx));
+    V3 t01 = texel(base + tiledOffset(x0, y1, tx)), t11 = texel(base + tiledOffset(x1, y1, tx));
     return bilerp(t00, t10, t01, t11, fx, fy);
 }
 

@@ -23,6 +23,9 @@ void launchReferenceOrder(const SceneView& s, const okrt_render_data& rd, const 
 // One bilinear tap per output texel (okrt_ref_kernel.hip).
 void launchScaleTexture(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, hipStream_t stream);
 
+// Row-major RGBA8 slices -> the tiled layout the samplers read (okrt_ref_kernel.hip).
+void launchTileTextures(const void* src, void* dst, uint32_t slices, uint32_t W, uint32_t H, hipStream_t stream);
+
 // Known-answer probes of the device leaf functions (okrt_ref_kernel.hip, okrt_debug_kat).
 void launchKat(const SceneView& s, uint32_t op, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, hipStream_t stream);
 

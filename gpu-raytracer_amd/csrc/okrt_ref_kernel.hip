@@ -172,6 +172,23 @@ void launchReferenceOrder(const SceneView& s, const okrt_render_data& rd, const 
     hipLaunchKernelGGL(renderReferenceOrder, grid, dim3(256), 0, stream, s, rd, t, accum, result, counters);
 }
 
+// Row-major RGBA8 slices -> 4x4-texel tiles (okrt_device.h: tiledOffset). One thread per texel of the padded grid.
+__global__ __launch_bounds__(256) void tileTexturesKernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t slices, uint32_t W, uint32_t H) {
+    const uint32_t tx = (W + 3) >> 2, ty = (H + 3) >> 2;
+    const size_t perSlice = (size_t)tx * ty * 16, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= perSlice * slices) return;
+    const uint32_t slice = (uint32_t)(i / perSlice);
+    const size_t r = i - (size_t)slice * perSlice;
+    const uint32_t tile = (uint32_t)(r >> 4), in = (uint32_t)(r & 15);
+    const uint32_t x = (tile % tx) * 4 + (in & 3), y = (tile / tx) * 4 + (in >> 2);
+    dst[i] = (x < W && y < H) ? src[((size_t)slice * H + y) * W + x] : 0u;
+}
+
+void launchTileTextures(const void* src, void* dst, uint32_t slices, uint32_t W, uint32_t H, hipStream_t stream) {
+    const size_t n = (size_t)((W + 3) >> 2) * ((H + 3) >> 2) * 16 * slices;
+    if (n) hipLaunchKernelGGL(tileTexturesKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, slices, W, H);
+}
+
 void launchScaleTexture(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh, hipStream_t stream) {
     dim3 grid((dw + 63) / 64, (dh + 3) / 4);
     hipLaunchKernelGGL(scaleTextureKernel, grid, dim3(256), 0, stream, src, sw, sh, dst, dw, dh);
