@@ -16,7 +16,7 @@ for builder, label in ((abi.BUILDER_HOST, "host SAH"), (abi.BUILDER_DEVICE, "dev
     bi = rt.ctx.build_info()
     rt.resetAccumulation()
     rt.ctx.set_option(abi.OPT_COUNTERS, 1); rt.ctx.reset_counters(); rt.render(); c = rt.ctx.counters(); rt.ctx.set_option(abi.OPT_COUNTERS, 0)
-    rt.renderFrames(32)
+    rt.renderFrames(64)
     rt.ctx.timer_begin(); rt.renderFrames(64); rt.ctx.timer_end(); ms = rt.ctx.timer_elapsed_ms() / 64
     print(f"{name} {label:18s} build {bi['device_ms']:8.2f} ms device / {wall:8.2f} ms wall  nodes {bi['num_nodes']:7d} tris {bi['num_triangles']:7d} depth {bi['max_depth']:3d}"
           f"  visits/ray {c['fast_nodes']/c['segments']:.1f}+{c['fast_tris']/c['segments']:.1f}  {ms:.3f} ms/frame", flush=True)
