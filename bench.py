@@ -287,6 +287,8 @@ def main():
     trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
     ctx.set_option(abi.OPT_TIMING, 0)
     rays_local = ctx.counters()["segments"]
+    if args.traversal == "reference":  # the reference-order kernel only counts with OKRT_OPT_COUNTERS (slow): segments of the counted frame x frames
+        rays_local = ref_counters["segments"] * steps_here
     # for reference: the same frames issued one okrt_render call per frame (the reference's main-loop shape)
     single_ms = single_sync_ms = None
     if world == 1 and not args.no_single_call:
