@@ -266,8 +266,9 @@ def main():
                 gather_tiles()
 
     run_frames(args.warmup, False)
-    if args.warmup % fpl:  # also warm the buffers of a full-size launch set (untimed)
-        run_frames(fpl, False)
+    # also run one full-size launch set untimed unless the warm-up already did: its queues (GBs) are allocated on first use
+    extra_warm = fpl if (args.warmup == 0 or args.warmup % fpl) else 0
+    run_frames(extra_warm, False)
     steps_here = args.steps
     if samples_split:  # rank r renders frame indices r*K/N + 1 ... (r+1)*K/N of a fresh accumulation
         assert args.steps % world == 0, "--split samples needs steps divisible by the number of ranks"
@@ -329,7 +330,7 @@ def main():
         else:
             tiling = importlib.import_module("gpu-raytracer_amd.tiling")
             full = tiling.deinterleave(gathered, H, STRIPE_ROWS)
-            frames_done = args.warmup + (fpl if args.warmup % fpl else 0) + args.steps
+            frames_done = args.warmup + extra_warm + args.steps
         assert bool((full[..., 3] == frames_done).all()), "combined frame: accumulation alpha != number of frames"
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
