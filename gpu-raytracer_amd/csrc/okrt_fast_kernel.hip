@@ -39,6 +39,39 @@ namespace okrt {
 
 namespace {
 
+// Streaming accesses (ray queues, hit records, radiance slots: written once, read once, GBs per launch set) carry the
+// non-temporal hint so that they do not evict what IS reused — nodes, triangles, shading records, textures — from L2 and
+// the Infinity Cache.
+typedef float nt4_t __attribute__((ext_vector_type(4)));
+typedef float nt2_t __attribute__((ext_vector_type(2)));
+#ifdef OKRT_NO_NT
+__device__ __forceinline__ float4 ldStream(const float4* p) { return *p; }
+__device__ __forceinline__ float2 ldStream(const float2* p) { return *p; }
+__device__ __forceinline__ uint32_t ldStream(const uint32_t* p) { return *p; }
+__device__ __forceinline__ void stStream(float4* p, float4 v) { *p = v; }
+__device__ __forceinline__ void stStream(float2* p, float2 v) { *p = v; }
+__device__ __forceinline__ void stStream(uint32_t* p, uint32_t v) { *p = v; }
+#else
+__device__ __forceinline__ float4 ldStream(const float4* p) {
+    const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 ldStream(const float2* p) {
+    const nt2_t v = __builtin_nontemporal_load(reinterpret_cast<const nt2_t*>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t ldStream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stStream(float4* p, float4 v) {
+    const nt4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt4_t*>(p));
+}
+__device__ __forceinline__ void stStream(float2* p, float2 v) {
+    const nt2_t w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt2_t*>(p));
+}
+__device__ __forceinline__ void stStream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#endif
+
 constexpr int kTraceThreads = 256;
 #ifndef OKRT_LDS_STACK
 #define OKRT_LDS_STACK 10
@@ -109,8 +142,8 @@ __global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileV
         ray = primaryRay(rd, rd.numAccumulationFrames + f, px, tile.globalRow(lrow), seed);
         pix = f * (tile.rows * tile.W) + lrow * tile.W + px;
     }
-    q.a[i] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x);
-    q.b[i] = make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix));
+    stStream(&q.a[i], make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x));
+    stStream(&q.b[i], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
 }
 
 template <bool COUNT>
@@ -176,8 +209,8 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             nRefill++;
 #endif
             if (cur == kDone && rayIdx != kInvalid) {
-                hb.h[rayIdx] = make_float4(best, hbu, hbv, __uint_as_float(hitIdx));
-                hb.tri[rayIdx] = hitTri;
+                stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
+                stStream(&hb.tri[rayIdx], hitTri);
                 rayIdx = kInvalid;
             }
             for (int round = 0; round < 2 && !exhausted; ++round) {
@@ -229,7 +262,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (cur == kDone && rank < avail) {
                     const uint32_t mine = resNext + rank;
-                    const float4 A = q.a[mine], B = q.b[mine];
+                    const float4 A = ldStream(&q.a[mine]), B = ldStream(&q.b[mine]);
                     Ray ray;
                     ray.origin = mk(A.x, A.y, A.z);
                     ray.direction = mk(A.w, B.x, B.y);
@@ -473,8 +506,8 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
     uint32_t base = acquire();
     float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
     if (base != kInvalid) {
-        A = q.a[base + lane];
-        B = q.b[base + lane];
+        A = ldStream(&q.a[base + lane]);
+        B = ldStream(&q.b[base + lane]);
     }
     uint32_t nextBase = kInvalid;
     float4 nA = A, nB = B;
@@ -488,8 +521,8 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
         const uint32_t mine = base + lane;
         nextBase = acquire();
         if (nextBase != kInvalid) {  // in flight during the traversal below
-            nA = q.a[nextBase + lane];
-            nB = q.b[nextBase + lane];
+            nA = ldStream(&q.a[nextBase + lane]);
+            nB = ldStream(&q.b[nextBase + lane]);
         }
         Ray ray;
         ray.origin = mk(A.x, A.y, A.z);
@@ -596,8 +629,8 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
             cur = stack[sp];  // same address in every lane (broadcast); written by lane 0 above
         }
         if (valid) {
-            hb.h[mine] = make_float4(best, hbu, hbv, __uint_as_float(hitIdx));
-            hb.tri[mine] = hitTri;
+            stStream(&hb.h[mine], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
+            stStream(&hb.tri[mine], hitTri);
         }
     }
 #ifdef OKRT_STAMPS
@@ -637,27 +670,27 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
     uint32_t seed = 0, pix = 0;
     bool valid = i < total;
     if (valid) {
-        const float4 A = qIn.a[i], B = qIn.b[i];
+        const float4 A = ldStream(&qIn.a[i]), B = ldStream(&qIn.b[i]);
         ray.origin = mk(A.x, A.y, A.z);
         ray.direction = mk(A.w, B.x, B.y);
         seed = __float_as_uint(B.z);
         pix = __float_as_uint(B.w);
         valid = pix != kInvalid;
         if (!FIRST) {  // camera rays start with throughput 1 and no radiance; later segments carry them
-            const float4 C = qIn.c[i];
-            const float2 D = qIn.d[i];
+            const float4 C = ldStream(&qIn.c[i]);
+            const float2 D = ldStream(&qIn.d[i]);
             contribution = mk(C.x, C.y, C.z);
             light = mk(C.w, D.x, D.y);
         }
     }
     if (valid) {
-        float4 H = hb.h[i];
+        float4 H = ldStream(&hb.h[i]);
         Hit h;
         h.distance = H.x;
         h.bu = H.y;
         h.bv = H.z;
         h.hitIdx = __float_as_uint(H.w);
-        h.triIdx = hb.tri[i];
+        h.triIdx = ldStream(&hb.tri[i]);
         h.hitType = h.triIdx != kInvalid ? 1u : 0u;
         Surface sf = shadeFetch(s, ray, h, cnt);
         addLights(s, rd, ray, sf, bounce, contribution, light, seed);
@@ -668,7 +701,7 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
             alive = bounce < lastBounce;
         }
         if (!alive) {
-            if (radiance) radiance[pix] = make_float4(light.x, light.y, light.z, 1.f);  // several frames in flight: added in frame order later
+            if (radiance) stStream(&radiance[pix], make_float4(light.x, light.y, light.z, 1.f));  // several frames in flight: added in frame order later
             else writePixel(rd, light, 0, 0, accum, result, pix);
         }
     }
@@ -688,10 +721,10 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
         uint32_t before = 0;
         for (uint32_t w = 0; w < wave; ++w) before += sWaveCount[w];
         const uint32_t o = shard * in.cap + sBlockBase + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        qOut.a[o] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x);
-        qOut.b[o] = make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix));
-        qOut.c[o] = make_float4(contribution.x, contribution.y, contribution.z, light.x);
-        qOut.d[o] = make_float2(light.y, light.z);
+        stStream(&qOut.a[o], make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x));
+        stStream(&qOut.b[o], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
+        stStream(&qOut.c[o], make_float4(contribution.x, contribution.y, contribution.z, light.x));
+        stStream(&qOut.d[o], make_float2(light.y, light.z));
     }
     if (COUNT && counters) {
         uint32_t vals[5] = {(FIRST && valid) ? 1u : 0u, cnt.meshHits, cnt.sphereHits, cnt.texTaps, cnt.envTaps};
@@ -713,7 +746,7 @@ __global__ __launch_bounds__(256) void accumulateKernel(okrt_render_data rd, uin
     if (p >= pixels) return;
     float4 a = accum[p];
     for (uint32_t f = 0; f < frames; ++f) {
-        const float4 r = radiance[(size_t)f * pixels + p];
+        const float4 r = ldStream(&radiance[(size_t)f * pixels + p]);
         a.x += r.x; a.y += r.y; a.z += r.z; a.w += 1.f;
     }
     accum[p] = a;
