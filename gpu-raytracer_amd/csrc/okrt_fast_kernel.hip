@@ -76,6 +76,9 @@ constexpr int kTraceThreads = 256;
 #ifndef OKRT_LDS_STACK
 #define OKRT_LDS_STACK 10
 #endif
+#ifndef OKRT_PACKET_WAVES
+#define OKRT_PACKET_WAVES 5
+#endif
 #ifndef OKRT_TRACE_WAVES
 #define OKRT_TRACE_WAVES 7
 #endif
@@ -118,6 +121,20 @@ struct FastView {
     uint2* overflow;       // per-thread spill slab
     uint32_t overflowCap;  // entries per thread
 };
+
+// Shading of one path segment from its hit record (RaytracerCS.hlsl:440-513): surface fetch, lights, environment on a
+// miss, BSDF sample. Updates ray / throughput / radiance / RNG state in place; returns true when the path continues.
+OKRT_DEV bool shadeSegment(const SceneView& s, const okrt_render_data& rd, Ray& ray, const Hit& h, uint32_t bounce, uint32_t lastBounce,
+                           V3& contribution, V3& light, uint32_t& seed, PathCounters& cnt) {
+    Surface sf = shadeFetch(s, ray, h, cnt);
+    addLights(s, rd, ray, sf, bounce, contribution, light, seed);
+    if (!sf.hit) {
+        light = fma3(sampleEnvironment(s, ray.direction, cnt), contribution, light);  // RaytracerCS.hlsl:489-493
+        return false;
+    }
+    scatter(sf, ray, contribution, light, seed);  // :495-513 (also on the last segment: emission is added here)
+    return bounce < lastBounce;
+}
 
 // primary ray index -> pixel (8x8 tiles, row-major over tiles)
 OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t& lrow) {
@@ -449,14 +466,29 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
 // (ties aside). Used for segment 0 only; bounce rays are incoherent and stay on the per-ray kernel.
 constexpr int kPacketStack = 128;  // shared entries per wave (>= 3 * tree depth + 4, checked on the host)
 
-template <bool COUNT>
-__global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* __restrict__ nodes, const float4* __restrict__ tris,
+// FUSED: the whole camera segment in this kernel — the rays are generated here instead of being read from queue 0, and
+// after the traversal the same wave shades its 64 hits and appends the surviving paths to queue 1. Against the
+// generate / trace / shade kernel triple this removes 136 bytes per pixel and frame of queue and hit-record traffic and
+// lets the issue-bound traversal of some waves overlap the memory-bound shading of others.
+struct FusedArgs {
+    uint32_t perFrame;        // queue positions per frame (tile padding included)
+    RayQueue qOut;            // queue 1
+    uint32_t* outCounts;      // its per-shard append counters
+    uint32_t lastBounce;
+    float4* accum;
+    uint32_t* result;
+    float4* radiance;
+};
+template <bool COUNT, bool FUSED>
+__global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_PACKET_WAVES))) void tracePacketKernel(const uint4* __restrict__ nodes, const float4* __restrict__ tris,
                                                                   SceneView s, okrt_render_data rd, TileView tile, RayQueue q, HitBuffer hb,
                                                                   ShardView sv, uint32_t cameraFrames, unsigned long long* counters,
-                                                                  unsigned long long* rayTotals) {
+                                                                  unsigned long long* rayTotals, FusedArgs fa) {
     __shared__ uint32_t sShared[kTraceThreads / 64][kPacketStack];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* stack = sShared[wave];
+    PathCounters shadeCnt = {};
+    uint32_t nPixels = 0;
     if (!COUNT && blockIdx.x == 0 && tid == 0) {
         const unsigned long long n = (unsigned long long)tile.W * tile.rows * cameraFrames;
         atomicAdd(&rayTotals[0], n);
@@ -505,7 +537,7 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
     };
     uint32_t base = acquire();
     float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
-    if (base != kInvalid) {
+    if (!FUSED && base != kInvalid) {
         A = ldStream(&q.a[base + lane]);
         B = ldStream(&q.b[base + lane]);
     }
@@ -520,14 +552,26 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
     for (; base != kInvalid; base = nextBase, A = nA, B = nB) {  // (the hand-over sits at the END of an iteration: no early wait)
         const uint32_t mine = base + lane;
         nextBase = acquire();
-        if (nextBase != kInvalid) {  // in flight during the traversal below
+        if (!FUSED && nextBase != kInvalid) {  // in flight during the traversal below
             nA = ldStream(&q.a[nextBase + lane]);
             nB = ldStream(&q.b[nextBase + lane]);
         }
         Ray ray;
-        ray.origin = mk(A.x, A.y, A.z);
-        ray.direction = mk(A.w, B.x, B.y);
-        const bool valid = __float_as_uint(B.w) != kInvalid;
+        uint32_t seed = 0, pix = kInvalid;
+        if (FUSED) {  // generateKernel's work: position -> (frame, pixel) -> camera ray
+            const uint32_t f = mine / fa.perFrame, ii = mine - f * fa.perFrame;
+            uint32_t px, lrow;
+            ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
+            if (primaryPixel(tile, ii, px, lrow)) {
+                ray = primaryRay(rd, rd.numAccumulationFrames + f, px, tile.globalRow(lrow), seed);
+                pix = f * (tile.rows * tile.W) + lrow * tile.W + px;
+            }
+        } else {
+            ray.origin = mk(A.x, A.y, A.z);
+            ray.direction = mk(A.w, B.x, B.y);
+            pix = __float_as_uint(B.w);
+        }
+        const bool valid = pix != kInvalid;
         if (__ballot(valid) == 0ull) continue;
         if (valid) nSeg++;
         const V3 ro = ray.origin;
@@ -628,9 +672,53 @@ __global__ __launch_bounds__(kTraceThreads) void tracePacketKernel(const uint4* 
             --sp;
             cur = stack[sp];  // same address in every lane (broadcast); written by lane 0 above
         }
-        if (valid) {
-            stStream(&hb.h[mine], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
-            stStream(&hb.tri[mine], hitTri);
+        if (!FUSED) {
+            if (valid) {
+                stStream(&hb.h[mine], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
+                stStream(&hb.tri[mine], hitTri);
+            }
+        } else {  // shadeKernel<FIRST>'s work on the hits this wave holds in registers
+            bool alive = false;
+            V3 contribution = mk(1.f, 1.f, 1.f), light = mk(0.f, 0.f, 0.f);
+            if (valid) {
+                nPixels++;
+                Hit h;
+                h.distance = best;
+                h.bu = hbu;
+                h.bv = hbv;
+                h.hitIdx = hitIdx;
+                h.triIdx = hitTri;
+                h.hitType = hitTri != kInvalid ? 1u : 0u;
+                alive = shadeSegment(s, rd, ray, h, 0u, fa.lastBounce, contribution, light, seed, shadeCnt);
+                if (!alive) {
+                    if (fa.radiance) stStream(&fa.radiance[pix], make_float4(light.x, light.y, light.z, 1.f));
+                    else writePixel(rd, light, 0, 0, fa.accum, fa.result, pix);
+                }
+            }
+            const unsigned long long am = __ballot(alive);
+            if (am) {  // survivors stay in the shard their tile came from: one atomic per wave and tile
+                const uint32_t tileShard = mine / sv.cap;
+                uint32_t obase = 0;
+                if (lane == 0) obase = atomicAdd(&fa.outCounts[tileShard * kCursorStride], (uint32_t)__popcll(am));
+                obase = __builtin_amdgcn_readfirstlane(obase);
+                if (alive) {
+                    const uint32_t o = tileShard * sv.cap + obase + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+                    stStream(&fa.qOut.a[o], make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x));
+                    stStream(&fa.qOut.b[o], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
+                    stStream(&fa.qOut.c[o], make_float4(contribution.x, contribution.y, contribution.z, light.x));
+                    stStream(&fa.qOut.d[o], make_float2(light.y, light.z));
+                }
+            }
+        }
+    }
+    if (FUSED && COUNT && counters) {  // what shadeKernel<FIRST, COUNT> reports
+        uint32_t vals[5] = {nPixels, shadeCnt.meshHits, shadeCnt.sphereHits, shadeCnt.texTaps, shadeCnt.envTaps};
+        const int slot[5] = {0, 6, 7, 8, 9};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint32_t v = vals[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
         }
     }
 #ifdef OKRT_STAMPS
@@ -692,14 +780,7 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
         h.hitIdx = __float_as_uint(H.w);
         h.triIdx = ldStream(&hb.tri[i]);
         h.hitType = h.triIdx != kInvalid ? 1u : 0u;
-        Surface sf = shadeFetch(s, ray, h, cnt);
-        addLights(s, rd, ray, sf, bounce, contribution, light, seed);
-        if (!sf.hit) {
-            light = fma3(sampleEnvironment(s, ray.direction, cnt), contribution, light);  // RaytracerCS.hlsl:489-493
-        } else {
-            scatter(sf, ray, contribution, light, seed);  // :495-513 (also on the last segment: emission is added here)
-            alive = bounce < lastBounce;
-        }
+        alive = shadeSegment(s, rd, ray, h, bounce, lastBounce, contribution, light, seed, cnt);
         if (!alive) {
             if (radiance) stStream(&radiance[pix], make_float4(light.x, light.y, light.z, 1.f));  // several frames in flight: added in frame order later
             else writePixel(rd, light, 0, 0, accum, result, pix);
@@ -1033,25 +1114,36 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
                          fs.counts + kCursorBase + b * kShards * kCursorStride};
     };
     mark();
-    // segment 0: camera rays into q[0] (a, b only), then the same trace kernel as every other segment
-    hipLaunchKernelGGL(generateKernel, sg, dim3(256), 0, stream, rd, t, fs.q[0], perFrame, frames);
     static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
+    static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
     const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
-    const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (29 VGPRs, 2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
-    if (packet && cnt)
-        hipLaunchKernelGGL((tracePacketKernel<true>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
-    else if (packet)
-        hipLaunchKernelGGL((tracePacketKernel<false>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
-    else if (cnt)
-        hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
-    else
-        hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
-    mark();
-    if (cnt)
-        hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
-    else
-        hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
+    const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
+    const FusedArgs fa{perFrame, fs.q[1], fs.counts + kShards * kCursorStride, lastBounce, accum, result, radiance};
+    if (packet && envFused) {
+        // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
+        if (cnt)
+            hipLaunchKernelGGL((tracePacketKernel<true, true>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        else
+            hipLaunchKernelGGL((tracePacketKernel<false, true>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
+    } else {
+        // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
+        hipLaunchKernelGGL(generateKernel, sg, dim3(256), 0, stream, rd, t, fs.q[0], perFrame, frames);
+        if (packet && cnt)
+            hipLaunchKernelGGL((tracePacketKernel<true, false>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        else if (packet)
+            hipLaunchKernelGGL((tracePacketKernel<false, false>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        else if (cnt)
+            hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+        else
+            hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+        mark();
+        if (cnt)
+            hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
+        else
+            hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
+    }
     if (lastBounce == 0 && radiance)
         hipLaunchKernelGGL(accumulateKernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, rd, (uint32_t)pixels, frames, radiance, accum, result);
     mark();
