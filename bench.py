@@ -358,7 +358,7 @@ def main():
                        "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "
                                   f"every {GATHER_EVERY} frames + final") if world > 1 else "none"},
             "roofline": {
-                "bound": "hbm", "kernel": "generateKernel + tracePacketKernel (camera rays) + traceKernel (bounce rays): BVH traversal of all segments of one frame, per GPU",
+                "bound": "hbm", "kernel": "camera-segment kernel (ray generation + packet traversal + first shading, fused) + traceKernel (bounce rays), per GPU; the traversal time therefore includes the camera segment's shading",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
                 "algorithmic_bytes_per_frame": trav_bytes, "algorithmic_bytes_per_ray": round(trav_bytes / max(ref_counters["segments"], 1), 1),

@@ -16,7 +16,7 @@ run tccB TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_
 python3 - <<PY
 import csv, glob, collections, re
 def short(name):
-    m = re.search(r"(tracePacketKernel<\w+>|traceKernel<\w+>|shadeKernel<\w+, \w+>|generateKernel|renderReferenceOrder)", name)
+    m = re.search(r"(tracePacketKernel<\w+, \w+>|tracePacketKernel<\w+>|traceKernel<\w+>|shadeKernel<\w+, \w+>|generateKernel|renderReferenceOrder)", name)
     return m.group(1) if m else None
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/*/*_counter_collection.csv"):

@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, re, sys
 
 
 def short(name):
-    m = re.search(r"(tracePacketKernel<\w+>|traceKernel<\w+>|shadeKernel<\w+, \w+>|generateKernel|accumulateKernel|renderReferenceOrder|scaleTextureKernel|__amd_rocclr_\w+)", name)
+    m = re.search(r"(tracePacketKernel<\w+, \w+>|tracePacketKernel<\w+>|traceKernel<\w+>|shadeKernel<\w+, \w+>|generateKernel|accumulateKernel|renderReferenceOrder|scaleTextureKernel|__amd_rocclr_\w+)", name)
     return m.group(1) if m else name[:40]
 
 
