@@ -478,6 +478,7 @@ struct FusedArgs {
     float4* accum;
     uint32_t* result;
     float4* radiance;
+    const okrt_render_data* rdDev;  // the same RenderData in device memory: read where it is used instead of being held in SGPRs across the tile loop
 };
 template <bool COUNT, bool FUSED>
 __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_PACKET_WAVES))) void tracePacketKernel(const uint4* __restrict__ nodes, const float4* __restrict__ tris,
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             uint32_t px, lrow;
             ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
             if (primaryPixel(tile, ii, px, lrow)) {
-                ray = primaryRay(rd, rd.numAccumulationFrames + f, px, tile.globalRow(lrow), seed);
+                ray = primaryRay(*fa.rdDev, fa.rdDev->numAccumulationFrames + f, px, tile.globalRow(lrow), seed);
                 pix = f * (tile.rows * tile.W) + lrow * tile.W + px;
             }
         } else {
@@ -689,10 +690,10 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 h.hitIdx = hitIdx;
                 h.triIdx = hitTri;
                 h.hitType = hitTri != kInvalid ? 1u : 0u;
-                alive = shadeSegment(s, rd, ray, h, 0u, fa.lastBounce, contribution, light, seed, shadeCnt);
+                alive = shadeSegment(s, *fa.rdDev, ray, h, 0u, fa.lastBounce, contribution, light, seed, shadeCnt);
                 if (!alive) {
                     if (fa.radiance) stStream(&fa.radiance[pix], make_float4(light.x, light.y, light.z, 1.f));
-                    else writePixel(rd, light, 0, 0, fa.accum, fa.result, pix);
+                    else writePixel(*fa.rdDev, light, 0, 0, fa.accum, fa.result, pix);
                 }
             }
             const unsigned long long am = __ballot(alive);
@@ -871,6 +872,7 @@ struct FastScene {
     uint32_t overflowCap = 0;
     int traceBlocks = 0, cus = 0;
     size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
+    okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
     float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
     size_t radianceCap = 0;
 };
@@ -1048,7 +1050,7 @@ void fastDestroy(FastScene* fs) {
     fs->nodes.release();
     fs->tris.release();
     if (fs->builder) deviceBuilderDestroy(fs->builder);
-    for (void* p : {(void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
+    for (void* p : {(void*)fs->rdDev, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
         if (p) hipFree(p);
     for (RayQueue& q : fs->q)
         for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
@@ -1119,7 +1121,9 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
     const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
-    const FusedArgs fa{perFrame, fs.q[1], fs.counts + kShards * kCursorStride, lastBounce, accum, result, radiance};
+    if (!fs.rdDev && !devAlloc(&fs.rdDev, 1, err)) return false;
+    hipMemcpyAsync(fs.rdDev, &rd, sizeof(rd), hipMemcpyHostToDevice, stream);  // stream order: the previous launch set has read its copy
+    const FusedArgs fa{perFrame, fs.q[1], fs.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, fs.rdDev};
     if (packet && envFused) {
         // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
         if (cnt)
