@@ -244,9 +244,10 @@ okrt_status okrt_timer_elapsed_ms(okrt_ctx* ctx, float* out_ms);
  * were traced together (okrt_render_frames, deferred okrt_render calls). */
 okrt_status okrt_last_render_ms(okrt_ctx* ctx, float* out_ms);
 /* With OKRT_OPT_TIMING = n: device time summed over the renders still in the ring (at most n), split
- * by kernel family: out_ms[0] = traversal kernels (trace primary + queued, or the reference-order
- * megakernel), out_ms[1] = shading kernels, out_ms[2] = everything else inside the frame (memsets,
- * gaps). *out_frames = number of renders summed. Synchronises. */
+ * by kernel family: out_ms[0] = traversal kernels (the camera-segment kernel — which generates, traces AND shades
+ * the camera rays — plus the trace kernels of the later segments; or the reference-order megakernel),
+ * out_ms[1] = the shading kernels of the later segments, out_ms[2] = everything else inside the frame (memsets,
+ * gaps). *out_frames = number of frames summed. Synchronises. */
 okrt_status okrt_get_stage_ms(okrt_ctx* ctx, float out_ms[3], uint32_t* out_frames);
 
 /* Validates the uploaded tables and (re)builds the derived traversal structure now instead of inside the next
