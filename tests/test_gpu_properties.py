@@ -321,3 +321,54 @@ def test_launch_sets_shrink_to_the_queue_memory_budget():
     rt.renderFrames(5)
     assert np.array_equal(rt.ctx.read_accum()[..., 3], np.full((180, 320), 5.0, np.float32))
     rt.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_call_sequences_deferred_equals_immediate(seed):
+    """API fuzz: the same random sequence of host calls — frames, batched frames, read-backs, option changes, DOF edits,
+    accumulation resets / toggles, tile changes, a resize, an entity move — drives one context with deferral (32) and
+    one without; every observation and the final framebuffers must be identical."""
+    desc = scenes.small_mesh_scene(seed=30 + seed, n_objects=5, detail=8, with_lights=True, octree=(0, 50))
+
+    def run(defer):
+        rng = np.random.default_rng(seed)
+        rt, sc, res = scenes.instantiate(desc, 192, 108)
+        rt.ctx.set_option(abi.OPT_DEFER, defer)
+        seen = []
+        for _ in range(60):
+            op = int(rng.integers(0, 12))
+            if op <= 3:
+                for _ in range(int(rng.integers(1, 9))):
+                    rt.render()
+            elif op == 4:
+                rt.renderFrames(int(rng.integers(1, 40)))
+            elif op == 5:
+                seen.append(rt.ctx.read_accum().copy())
+            elif op == 6:
+                rt.setDOF(float(rng.uniform(0, 1)), float(rng.uniform(5, 20)))
+            elif op == 7:
+                rt.resetAccumulation()
+            elif op == 8:
+                rt.ctx.set_option(abi.OPT_MAX_BOUNCES, int(rng.integers(0, 4)))
+            elif op == 9:
+                n = int(rng.integers(1, 4))
+                rt.ctx.set_tile(8, int(rng.integers(0, n)), n)
+                rt.resetAccumulation()
+            elif op == 10:
+                sc.set_transform(0, position=tuple(rng.uniform(-4, 4, 3)), rotation=(0.0, float(rng.uniform(0, 90)), 0.0))
+                rt.createOctTree(sc, 0, 50)
+                rt.resetAccumulation()
+            else:
+                seen.append(rt.ctx.counters()["pixels"])
+        seen.append(rt.ctx.read_accum().copy())
+        seen.append(rt.ctx.read_result().copy())
+        rt.close()
+        return seen
+
+    a, b = run(32), run(0)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        if isinstance(x, np.ndarray):
+            assert x.shape == y.shape and np.array_equal(x, y, equal_nan=(x.dtype.kind == "f"))
+        else:
+            assert x == y
