@@ -1,5 +1,5 @@
 // okrt_fast.h — the MI355X traversal structure derived from the uploaded reference tables, and
-// the wavefront pipeline that traces it (okrt_fast_build.cpp, okrt_fast_kernel.hip).
+// the wavefront pipeline that traces it (okrt_fast_build.cpp, okrt_fast_build_device.hip; okrt_fast_pipeline.hip + okrt_fast_trace.hip + okrt_fast_shade.hip).
 //
 // Layout in HBM (all 16-byte aligned, 128-byte node stride = one L2 line per node visit):
 //   Node4Q   64 B  four child boxes, 8-bit planes on a per-node power-of-two grid, child[4] references.

@@ -1,0 +1,149 @@
+// okrt_fast_internal.h — what the three translation units of the wavefront pipeline share (okrt_fast_pipeline.hip,
+// okrt_fast_trace.hip, okrt_fast_shade.hip): queue views, tunables, the per-segment shading function, and the
+// host-side launch wrappers of the kernels each unit defines. Not part of any public interface.
+#pragma once
+#include "okrt_fast.h"
+
+namespace okrt {
+namespace fastdetail {
+
+// Streaming accesses (ray queues, hit records, radiance slots: written once, read once, GBs per launch set) carry the
+// non-temporal hint so that they do not evict what IS reused — nodes, triangles, shading records, textures — from L2 and
+// the Infinity Cache.
+typedef float nt4_t __attribute__((ext_vector_type(4)));
+typedef float nt2_t __attribute__((ext_vector_type(2)));
+#ifdef OKRT_NO_NT
+__device__ __forceinline__ float4 ldStream(const float4* p) { return *p; }
+__device__ __forceinline__ float2 ldStream(const float2* p) { return *p; }
+__device__ __forceinline__ uint32_t ldStream(const uint32_t* p) { return *p; }
+__device__ __forceinline__ void stStream(float4* p, float4 v) { *p = v; }
+__device__ __forceinline__ void stStream(float2* p, float2 v) { *p = v; }
+__device__ __forceinline__ void stStream(uint32_t* p, uint32_t v) { *p = v; }
+#else
+__device__ __forceinline__ float4 ldStream(const float4* p) {
+    const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 ldStream(const float2* p) {
+    const nt2_t v = __builtin_nontemporal_load(reinterpret_cast<const nt2_t*>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t ldStream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stStream(float4* p, float4 v) {
+    const nt4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt4_t*>(p));
+}
+__device__ __forceinline__ void stStream(float2* p, float2 v) {
+    const nt2_t w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt2_t*>(p));
+}
+__device__ __forceinline__ void stStream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#endif
+
+constexpr int kTraceThreads = 256;
+#ifndef OKRT_LDS_STACK
+#define OKRT_LDS_STACK 10
+#endif
+#ifndef OKRT_PACKET_WAVES
+#define OKRT_PACKET_WAVES 5
+#endif
+#ifndef OKRT_TRACE_WAVES
+#define OKRT_TRACE_WAVES 7
+#endif
+constexpr int kLdsStack = OKRT_LDS_STACK;  // entries per lane kept in LDS
+constexpr int kRefillBelow = 40;     // refill idle lanes when fewer than this many lanes are active
+constexpr uint32_t kDone = kEmptyRef;
+constexpr uint32_t kShards = 8;      // queue shards = XCDs
+constexpr uint32_t kBatch = 64;      // rays a wave reserves per cursor atomic (sweep: 64 best with 5 blocks/CU)
+constexpr uint32_t kCursorStride = 32;  // words: one cursor per 128-byte line (device-scope atomics serialise per line)
+
+// A sharded queue: shard s owns positions [s*cap, s*cap + count(s)). Camera rays: count(s) follows
+// from `total`; queued rays: counts[] written by the shading kernel. cursors[] = next unreserved.
+struct ShardView {
+    uint32_t cap, total;
+    uint32_t batch, xcdAffinity, refillBelow;  // tunables (developer knobs: OKRT_FAST_BATCH / _AFFINITY / _REFILL)
+    uint32_t nodeMin, triMin;                  // a step block runs when at least this many lanes want it (OKRT_FAST_NODE_MIN / _TRI_MIN)
+    const uint32_t* counts;  // counts[s * kCursorStride]; nullptr for camera rays
+    uint32_t* cursors;       // cursors[s * kCursorStride]
+    __device__ uint32_t count(uint32_t s) const {
+        if (counts) return counts[s * kCursorStride];
+        const uint32_t lo = s * cap;
+        return total > lo ? min(total - lo, cap) : 0u;
+    }
+};
+
+struct RayQueue {        // SoA, capacity = owned pixels
+    float4* a;           // origin.xyz, dir.x
+    float4* b;           // dir.y, dir.z, seed (bits), framebuffer offset (bits)
+    float4* c;           // contribution.rgb, light.r
+    float2* d;           // light.g, light.b
+};
+struct HitBuffer {
+    float4* h;           // distance, bu, bv, hitIdx (bits)
+    uint32_t* tri;       // source triangle index (kInvalid for a sphere hit or a miss)
+};
+
+struct FastView {
+    const uint4* nodes;    // Node4Q as 4 x uint4
+    const float4* tris;    // Tri48 as 3 x float4
+    uint2* overflow;       // per-thread spill slab
+    uint32_t overflowCap;  // entries per thread
+};
+
+// Shading of one path segment from its hit record (RaytracerCS.hlsl:440-513): surface fetch, lights, environment on a
+// miss, BSDF sample. Updates ray / throughput / radiance / RNG state in place; returns true when the path continues.
+OKRT_DEV bool shadeSegment(const SceneView& s, const okrt_render_data& rd, Ray& ray, const Hit& h, uint32_t bounce, uint32_t lastBounce,
+                           V3& contribution, V3& light, uint32_t& seed, PathCounters& cnt) {
+    Surface sf = shadeFetch(s, ray, h, cnt);
+    addLights(s, rd, ray, sf, bounce, contribution, light, seed);
+    if (!sf.hit) {
+        light = fma3(sampleEnvironment(s, ray.direction, cnt), contribution, light);  // RaytracerCS.hlsl:489-493
+        return false;
+    }
+    scatter(sf, ray, contribution, light, seed);  // :495-513 (also on the last segment: emission is added here)
+    return bounce < lastBounce;
+}
+
+// primary ray index -> pixel (8x8 tiles, row-major over tiles)
+OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t& lrow) {
+    const uint32_t tilesX = (t.W + 7) >> 3;
+    const uint32_t tile = i >> 6, l = i & 63;
+    px = (tile % tilesX) * 8 + (l & 7);
+    lrow = (tile / tilesX) * 8 + (l >> 3);
+    return px < t.W && lrow < t.rows;
+}
+
+constexpr int kPacketStack = 128;  // shared entries per wave (>= 3 * tree depth + 4, checked on the host)
+
+// FUSED: the whole camera segment in this kernel — the rays are generated here instead of being read from queue 0, and
+// after the traversal the same wave shades its 64 hits and appends the surviving paths to queue 1. Against the
+// generate / trace / shade kernel triple this removes 136 bytes per pixel and frame of queue and hit-record traffic and
+// lets the issue-bound traversal of some waves overlap the memory-bound shading of others.
+struct FusedArgs {
+    uint32_t perFrame;        // queue positions per frame (tile padding included)
+    RayQueue qOut;            // queue 1
+    uint32_t* outCounts;      // its per-shard append counters
+    uint32_t lastBounce;
+    float4* accum;
+    uint32_t* result;
+    float4* radiance;
+    const okrt_render_data* rdDev;  // the same RenderData in device memory: read where it is used instead of being held in SGPRs across the tile loop
+};
+
+// ---- launch wrappers (one per kernel family; `count` selects the variant that feeds okrt_counters) --------------------
+void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames);
+void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
+                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals);
+void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,
+                  const okrt_render_data& rd, const TileView& tile, RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames,
+                  unsigned long long* counters, unsigned long long* rayTotals, const FusedArgs& fa);
+void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
+                 RayQueue qIn, HitBuffer hb, const ShardView& in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce, uint32_t lastBounce,
+                 float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters);
+void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t pixels, uint32_t frames, const float4* radiance, float4* accum,
+                      uint32_t* result);
+void launchFastKat(hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats,
+                   float* out, uint32_t outFloats);
+
+}  // namespace fastdetail
+}  // namespace okrt

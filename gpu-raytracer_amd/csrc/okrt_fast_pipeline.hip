@@ -1,0 +1,290 @@
+// okrt_fast_pipeline.hip — the MI355X wavefront path tracer (OKRT_TRAVERSAL_FAST).
+//
+// One frame = a short pipeline of kernels over ray queues in HBM (per path segment):
+//
+//   generateKernel         camera rays for the owned pixels of F frames, in 8x8-tile order, into ray queue 0 (32 B per ray)
+//   tracePacketKernel      camera rays: one wave walks the tree once for its 8x8 tile (wave-uniform node, scalar loads)
+//   traceKernel            every other segment: persistent waves, one node visit or triangle test per lane and
+//                          iteration ("if-if"), closest hit through the Node4Q/Tri48 structure, 20-byte hit record per ray
+//   shadeKernel            material/texture fetch, lights, BSDF sample; finished paths go to the framebuffer (or their
+//                          frame's radiance slot), survivors are compacted into the next ray queue (56 B per ray)
+//   traceKernel / shadeKernel   ... one pair per further segment;  accumulateKernel when F > 1
+//
+// Traversal (what the profile is dominated by) is built for CDNA4:
+//   * wave64, 256-thread blocks, persistent: each wave REFILLS its idle lanes when fewer than
+//     kRefillBelow lanes are still traversing (ballot + prefix-popcount ranks), so divergence in path
+//     length does not idle the SIMD. Rays come from kShards = 8 queue shards, one per XCD (a
+//     contiguous band of the image for camera rays): a wave reserves kBatch rays at a time from its
+//     own XCD's cursor (HW_REG_XCC_ID) and steals from the other shards when it runs dry. One shared
+//     cursor word saturates at ~90 atomics/us on MI355X and WAS the bottleneck of the first version;
+//     sharding + batching removes it and keeps each XCD's L2 on one region of the scene;
+//   * per-lane traversal stack in LDS ([entry][thread], conflict-free), entries carry the child's
+//     entry distance so stale entries are dropped without touching memory; deeper levels spill to
+//     a per-thread HBM slab (sized from the tree depth at build time);
+//   * one Node4Q visit = 4 x 16-byte loads (64 B, 8-bit child planes on a per-node grid, conservative);
+//     children are visited nearest first (4-key sorting network), a Tri48 test = 3 x 16-byte loads; a lane does
+//     one of the two per iteration and the loads of all lanes are issued together (see the loop body);
+//   * same arithmetic as the reference for what decides the result: the ray re-normalised as the
+//     shader does for each instance, Moeller-Trumbore with the
+//     shader's edge convention, hit distance = length(dir*t) (RaytracerCS.hlsl:276,285,306-316),
+//     so for identity instances (all benchmark scenes) the closest hit equals the reference's bit
+//     for bit; only equal-distance ties may resolve to a different triangle.
+// The kernels live in okrt_fast_trace.hip (traversal) and okrt_fast_shade.hip (generation, shading, accumulation);
+// this file owns the device-resident state and the launch sequence.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "okrt_fast_internal.h"
+
+namespace okrt {
+
+using namespace fastdetail;
+
+namespace {
+
+template <class T>
+bool devAlloc(T** p, size_t n, std::string& err) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    if (!n) return true;
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) {
+        err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+constexpr uint32_t kMaxSegments = 66;                       // max_bounces <= 64
+constexpr uint32_t kCursorBase = kMaxSegments * kShards * kCursorStride;
+constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorStride;
+
+struct FastScene {
+    DeviceArray<uint4> nodes;   // 4 x uint4 per Node4Q
+    DeviceArray<float4> tris;   // 3 x float4 per Tri48
+    uint32_t numNodes = 0, numTris = 0, maxDepth = 0;
+    bool allIdentity = true;
+    DeviceBuilder* builder = nullptr;  // device-side build scratch (okrt_fast_build_device.hip), made on first use
+    FastBuildInfo info = {};
+    // pipeline state, sized lazily for the tile
+    size_t capacity = 0;
+    RayQueue q[2] = {};
+    HitBuffer hb = {};
+    uint32_t* counts = nullptr;  // per segment b, shard s: count at (b*kShards + s)*kCursorStride, cursor at kCursorBase + the same
+                                 // (every counter on its own 128-byte line: device-scope atomics serialise per line)
+    uint2* overflow = nullptr;
+    uint32_t overflowCap = 0;
+    int traceBlocks = 0, cus = 0;
+    size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
+    okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
+    float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
+    size_t radianceCap = 0;
+};
+
+bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& tables, uint32_t builder, hipStream_t stream, std::string& err) {
+    if (!*scene) *scene = new FastScene();
+    FastScene& fs = **scene;
+    const auto t0 = std::chrono::steady_clock::now();
+    float deviceMs = 0.f;
+    if (builder == 1u) {
+        if (!fs.builder) fs.builder = deviceBuilderCreate();
+        FastDeviceResult r{fs.nodes, fs.tris};
+        if (!buildFastDevice(*fs.builder, in, tables, stream, r, err)) return false;
+        fs.numNodes = r.numNodes;
+        fs.numTris = r.numTris;
+        fs.maxDepth = r.maxDepth;
+        fs.allIdentity = r.allIdentity;
+        deviceMs = r.buildMs;
+    } else {
+        FastHostScene host;
+        buildFastHost(in, host);
+        fs.numNodes = (uint32_t)host.nodes.size();
+        fs.numTris = (uint32_t)host.tris.size();
+        fs.maxDepth = host.maxDepth;
+        fs.allIdentity = host.allIdentity;
+        if (!fs.nodes.need(host.nodes.size() * 4, err)) return false;
+        if (!fs.tris.need(std::max<size_t>(host.tris.size(), 1) * 3, err)) return false;
+        hipError_t e = hipMemcpyAsync(fs.nodes.p, host.nodes.data(), host.nodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && !host.tris.empty())
+            e = hipMemcpyAsync(fs.tris.p, host.tris.data(), host.tris.size() * sizeof(Tri48), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `host` dies at return
+        if (e != hipSuccess) {
+            err = std::string("upload: ") + hipGetErrorString(e);
+            return false;
+        }
+    }
+    fs.info = {builder, fs.numNodes, fs.numTris, fs.maxDepth, deviceMs,
+               std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()};
+    // spill slab: a visit pushes at most 3 entries, so 3*depth bounds the stack
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    fs.cus = cus;
+    fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : OKRT_TRACE_WAVES);
+    uint32_t need = 3 * fs.maxDepth + 4;
+    uint32_t cap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;
+    if (cap != fs.overflowCap || !fs.overflow) {
+        if (!devAlloc(&fs.overflow, (size_t)fs.traceBlocks * kTraceThreads * cap, err)) return false;
+        fs.overflowCap = cap;
+    }
+    if (!fs.counts && !devAlloc(&fs.counts, kCountWords, err)) return false;
+    return true;
+}
+
+bool fastKat(const FastScene* fs, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, hipStream_t stream,
+             std::string& err) {
+    if (!fs || !fs->nodes.p) {
+        err = "no structure built yet";
+        return false;
+    }
+    if (4 * fs->maxDepth + 4 > 256u) {
+        err = "tree too deep for the probe's private stack";
+        return false;
+    }
+    launchFastKat(stream, fs->nodes.p, fs->tris.p, s, n, in, inFloats, out, outFloats);
+    return true;
+}
+
+void fastSetQueueBudget(FastScene** scene, size_t bytes) {
+    if (!*scene) *scene = new FastScene();
+    (*scene)->queueBudgetBytes = bytes;
+}
+
+void fastBuildInfo(const FastScene* fs, FastBuildInfo* info) {
+    if (fs) *info = fs->info;
+    else std::memset(info, 0, sizeof(*info));
+}
+
+bool fastReadStructure(const FastScene* fs, void* nodes, uint32_t nodeCapacity, void* tris, uint32_t triCapacity, hipStream_t stream, std::string& err) {
+    if (!fs) {
+        err = "no structure built yet";
+        return false;
+    }
+    if ((nodes && nodeCapacity < fs->numNodes) || (tris && triCapacity < fs->numTris)) {
+        err = "capacity too small";
+        return false;
+    }
+    hipError_t e = hipSuccess;
+    if (nodes && fs->numNodes) e = hipMemcpyAsync(nodes, fs->nodes.p, (size_t)fs->numNodes * sizeof(Node4Q), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && tris && fs->numTris) e = hipMemcpyAsync(tris, fs->tris.p, (size_t)fs->numTris * sizeof(Tri48), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        err = std::string("read structure: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+void fastDestroy(FastScene* fs) {
+    if (!fs) return;
+    fs->nodes.release();
+    fs->tris.release();
+    if (fs->builder) deviceBuilderDestroy(fs->builder);
+    for (void* p : {(void*)fs->rdDev, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
+        if (p) hipFree(p);
+    for (RayQueue& q : fs->q)
+        for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
+            if (p) hipFree(p);
+    delete fs;
+}
+
+bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
+                unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
+                std::string& err) {
+    const uint32_t perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
+    if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)perFrame * frames > 0x7FFFFFFFull) {
+        err = "frames per launch out of range";
+        return false;
+    }
+    const uint32_t total = perFrame * frames;
+    const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
+    const size_t items = (size_t)cap * kShards;
+    // per item: two ray queues (16+16+16+8 B each) + hit record (16+4 B); per pixel and frame: a 16-byte radiance slot
+    const size_t needBytes = items * (2 * 56 + 20) + (frames > 1 ? (size_t)t.rows * t.W * frames * 16 : 0);
+    if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
+        err = "launch set exceeds the queue memory budget";
+        return false;
+    }
+    if (items > fs.capacity) {
+        hipStreamSynchronize(stream);
+        fs.capacity = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
+        for (RayQueue& q : fs.q)
+            if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return false;
+        if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return false;
+        fs.capacity = items;
+    }
+    const size_t pixels = (size_t)t.rows * t.W;
+    float4* radiance = nullptr;
+    if (frames > 1) {
+        if (pixels * frames > fs.radianceCap) {
+            hipStreamSynchronize(stream);
+            fs.radianceCap = 0;
+            if (!devAlloc(&fs.radiance, pixels * frames, err)) return false;
+            fs.radianceCap = pixels * frames;
+        }
+        radiance = fs.radiance;
+    }
+    const uint32_t lastBounce = s.maxBounces;
+    if (lastBounce + 2 > kMaxSegments) {
+        err = "max_bounces too large for the fast pipeline";
+        return false;
+    }
+    hipMemsetAsync(fs.counts, 0, (size_t)kCountWords * sizeof(uint32_t), stream);
+    FastView fv{fs.nodes.p, fs.tris.p, fs.overflow, fs.overflowCap};
+    const dim3 tg(fs.traceBlocks);
+    const dim3 sg((unsigned)(items / 256));
+    const bool cnt = counters != nullptr;
+    int ev = 0;
+    auto mark = [&]() { if (events) hipEventRecord(events[ev++], stream); };
+    static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
+    static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
+    static const uint32_t envNodeMin = getenv("OKRT_FAST_NODE_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_NODE_MIN")) : 32u;
+    static const uint32_t envTriMin = getenv("OKRT_FAST_TRI_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_TRI_MIN")) : 24u;
+    static const uint32_t envRefill = getenv("OKRT_FAST_REFILL") ? (uint32_t)atoi(getenv("OKRT_FAST_REFILL")) : (uint32_t)kRefillBelow;
+    auto shards = [&](uint32_t b, bool camera) {
+        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, envNodeMin, envTriMin, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
+                         fs.counts + kCursorBase + b * kShards * kCursorStride};
+    };
+    mark();
+    static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
+    static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
+    const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
+    static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
+    const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
+    if (!fs.rdDev && !devAlloc(&fs.rdDev, 1, err)) return false;
+    hipMemcpyAsync(fs.rdDev, &rd, sizeof(rd), hipMemcpyHostToDevice, stream);  // stream order: the previous launch set has read its copy
+    const FusedArgs fa{perFrame, fs.q[1], fs.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, fs.rdDev};
+    const uint32_t pixels32 = (uint32_t)pixels;
+    if (packet && envFused) {
+        // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
+        launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
+    } else {
+        // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
+        launchGenerate(sg, stream, rd, t, fs.q[0], perFrame, frames);
+        if (packet) launchPacket(cnt, false, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        else launchTrace(cnt, tg, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+        mark();
+        launchShade(true, cnt, sg, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result,
+                    radiance, counters);
+    }
+    if (lastBounce == 0 && radiance) launchAccumulate(stream, rd, pixels32, frames, radiance, accum, result);
+    mark();
+    // segments 1..lastBounce: queue b lives in q[b & 1]
+    for (uint32_t b = 1; b <= lastBounce; ++b) {
+        RayQueue& qin = fs.q[b & 1];
+        RayQueue& qout = fs.q[(b + 1) & 1];
+        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals);
+        mark();
+        launchShade(false, cnt, sg, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum,
+                    result, radiance, counters);
+        if (b == lastBounce && radiance) launchAccumulate(stream, rd, pixels32, frames, radiance, accum, result);
+        mark();
+    }
+    return true;
+}
+
+}  // namespace okrt

@@ -1,0 +1,144 @@
+// okrt_fast_shade.hip — the non-traversal kernels of the wavefront pipeline (okrt_fast_pipeline.hip has the overview):
+// camera-ray generation (unfused form), per-segment shading + queue compaction, in-order accumulation of frame slots.
+#include "okrt_fast_internal.h"
+
+namespace okrt {
+namespace fastdetail {
+namespace {
+
+// Camera rays for every owned pixel, in tile order (position i <-> pixel by primaryPixel): origin, direction,
+// RNG state after the 4 camera draws, framebuffer offset. Padding positions (outside the image) get pix = kInvalid.
+// With `frames` > 1 the positions of frame f follow those of frame f-1 and pix addresses the frame's radiance slot.
+__global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileView tile, RayQueue q, uint32_t perFrame, uint32_t frames) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= perFrame * frames) return;
+    const uint32_t f = i / perFrame, ii = i - f * perFrame;
+    uint32_t px, lrow, seed = 0, pix = kInvalid;
+    Ray ray;
+    ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
+    if (primaryPixel(tile, ii, px, lrow)) {
+        ray = primaryRay(rd, rd.numAccumulationFrames + f, px, tile.globalRow(lrow), seed);
+        pix = f * (tile.rows * tile.W) + lrow * tile.W + px;
+    }
+    stStream(&q.a[i], make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x));
+    stStream(&q.b[i], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
+}
+
+// Shading of one path segment. FIRST: items are pixels (tile order), the camera ray is regenerated.
+// Finished paths (miss, or last segment) accumulate; the rest are compacted into `qOut`.
+template <bool FIRST, bool COUNT>
+__global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data rd, TileView tile, RayQueue qIn, HitBuffer hb,
+                                                  ShardView in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce,
+                                                  uint32_t lastBounce, float4* accum, uint32_t* result, float4* radiance,
+                                                  unsigned long long* counters) {
+    // positions are [shard][cap]; cap is a multiple of 256, so a block (and a wave) never straddles shards
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const uint32_t shard = (blockIdx.x * 256) / in.cap;
+    const uint32_t total = shard * in.cap + in.count(shard);
+    PathCounters cnt = {};
+    bool alive = false;  // continues into the next segment
+    Ray ray;
+    V3 contribution = mk(1.f, 1.f, 1.f), light = mk(0.f, 0.f, 0.f);
+    uint32_t seed = 0, pix = 0;
+    bool valid = i < total;
+    if (valid) {
+        const float4 A = ldStream(&qIn.a[i]), B = ldStream(&qIn.b[i]);
+        ray.origin = mk(A.x, A.y, A.z);
+        ray.direction = mk(A.w, B.x, B.y);
+        seed = __float_as_uint(B.z);
+        pix = __float_as_uint(B.w);
+        valid = pix != kInvalid;
+        if (!FIRST) {  // camera rays start with throughput 1 and no radiance; later segments carry them
+            const float4 C = ldStream(&qIn.c[i]);
+            const float2 D = ldStream(&qIn.d[i]);
+            contribution = mk(C.x, C.y, C.z);
+            light = mk(C.w, D.x, D.y);
+        }
+    }
+    if (valid) {
+        float4 H = ldStream(&hb.h[i]);
+        Hit h;
+        h.distance = H.x;
+        h.bu = H.y;
+        h.bv = H.z;
+        h.hitIdx = __float_as_uint(H.w);
+        h.triIdx = ldStream(&hb.tri[i]);
+        h.hitType = h.triIdx != kInvalid ? 1u : 0u;
+        alive = shadeSegment(s, rd, ray, h, bounce, lastBounce, contribution, light, seed, cnt);
+        if (!alive) {
+            if (radiance) stStream(&radiance[pix], make_float4(light.x, light.y, light.z, 1.f));  // several frames in flight: added in frame order later
+            else writePixel(rd, light, 0, 0, accum, result, pix);
+        }
+    }
+    // ballot compaction of the surviving paths into the next queue: ranks inside the wave by ballot, waves inside
+    // the block through LDS, ONE atomic per block on the shard's counter (one per wave saturated the counter line)
+    __shared__ uint32_t sWaveCount[4], sBlockBase;
+    const unsigned long long m = __ballot(alive);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane == 0) sWaveCount[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = sWaveCount[0] + sWaveCount[1] + sWaveCount[2] + sWaveCount[3];
+        sBlockBase = tot ? atomicAdd(&outCounts[shard * kCursorStride], tot) : 0u;  // survivors stay in their shard
+    }
+    __syncthreads();
+    if (alive) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += sWaveCount[w];
+        const uint32_t o = shard * in.cap + sBlockBase + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        stStream(&qOut.a[o], make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x));
+        stStream(&qOut.b[o], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
+        stStream(&qOut.c[o], make_float4(contribution.x, contribution.y, contribution.z, light.x));
+        stStream(&qOut.d[o], make_float2(light.y, light.z));
+    }
+    if (COUNT && counters) {
+        uint32_t vals[5] = {(FIRST && valid) ? 1u : 0u, cnt.meshHits, cnt.sphereHits, cnt.texTaps, cnt.envTaps};
+        const int slot[5] = {0, 6, 7, 8, 9};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint32_t v = vals[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
+        }
+    }
+}
+
+// Adds the radiance slots of `frames` frames to the accumulation IN FRAME ORDER and resolves with the last frame's
+// count: exactly what `frames` consecutive single-frame passes do (RaytracerCS.hlsl:526-536).
+__global__ __launch_bounds__(256) void accumulateKernel(okrt_render_data rd, uint32_t pixels, uint32_t frames, const float4* radiance,
+                                                       float4* accum, uint32_t* result) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= pixels) return;
+    float4 a = accum[p];
+    for (uint32_t f = 0; f < frames; ++f) {
+        const float4 r = ldStream(&radiance[(size_t)f * pixels + p]);
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += 1.f;
+    }
+    accum[p] = a;
+    const float n = (float)(rd.numAccumulationFrames + frames - 1u);
+    result[p] = toUnorm8(a.x / n) | (toUnorm8(a.y / n) << 8) | (toUnorm8(a.z / n) << 16) | (toUnorm8(a.w / n) << 24);
+}
+
+}  // namespace
+
+void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames) {
+    hipLaunchKernelGGL(generateKernel, grid, dim3(256), 0, stream, rd, tile, q, perFrame, frames);
+}
+
+void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
+                 RayQueue qIn, HitBuffer hb, const ShardView& in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce, uint32_t lastBounce,
+                 float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters) {
+    const dim3 tb(256);
+    if (first && count) hipLaunchKernelGGL((shadeKernel<true, true>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
+    else if (first) hipLaunchKernelGGL((shadeKernel<true, false>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
+    else if (count) hipLaunchKernelGGL((shadeKernel<false, true>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
+    else hipLaunchKernelGGL((shadeKernel<false, false>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
+}
+
+void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t pixels, uint32_t frames, const float4* radiance, float4* accum,
+                      uint32_t* result) {
+    hipLaunchKernelGGL(accumulateKernel, dim3((pixels + 255) / 256), dim3(256), 0, stream, rd, pixels, frames, radiance, accum, result);
+}
+
+}  // namespace fastdetail
+}  // namespace okrt

@@ -1,167 +1,12 @@
-// okrt_fast_kernel.hip — the MI355X wavefront path tracer (OKRT_TRAVERSAL_FAST).
-//
-// One frame = a short pipeline of kernels over ray queues in HBM (per path segment):
-//
-//   generateKernel         camera rays for the owned pixels of F frames, in 8x8-tile order, into ray queue 0 (32 B per ray)
-//   tracePacketKernel      camera rays: one wave walks the tree once for its 8x8 tile (wave-uniform node, scalar loads)
-//   traceKernel            every other segment: persistent waves, one node visit or triangle test per lane and
-//                          iteration ("if-if"), closest hit through the Node4Q/Tri48 structure, 20-byte hit record per ray
-//   shadeKernel            material/texture fetch, lights, BSDF sample; finished paths go to the framebuffer (or their
-//                          frame's radiance slot), survivors are compacted into the next ray queue (56 B per ray)
-//   traceKernel / shadeKernel   ... one pair per further segment;  accumulateKernel when F > 1
-//
-// Traversal (what the profile is dominated by) is built for CDNA4:
-//   * wave64, 256-thread blocks, persistent: each wave REFILLS its idle lanes when fewer than
-//     kRefillBelow lanes are still traversing (ballot + prefix-popcount ranks), so divergence in path
-//     length does not idle the SIMD. Rays come from kShards = 8 queue shards, one per XCD (a
-//     contiguous band of the image for camera rays): a wave reserves kBatch rays at a time from its
-//     own XCD's cursor (HW_REG_XCC_ID) and steals from the other shards when it runs dry. One shared
-//     cursor word saturates at ~90 atomics/us on MI355X and WAS the bottleneck of the first version;
-//     sharding + batching removes it and keeps each XCD's L2 on one region of the scene;
-//   * per-lane traversal stack in LDS ([entry][thread], conflict-free), entries carry the child's
-//     entry distance so stale entries are dropped without touching memory; deeper levels spill to
-//     a per-thread HBM slab (sized from the tree depth at build time);
-//   * one Node4Q visit = 4 x 16-byte loads (64 B, 8-bit child planes on a per-node grid, conservative);
-//     children are visited nearest first (4-key sorting network), a Tri48 test = 3 x 16-byte loads; a lane does
-//     one of the two per iteration and the loads of all lanes are issued together (see the loop body);
-//   * same arithmetic as the reference for what decides the result: the ray re-normalised as the
-//     shader does for each instance, Moeller-Trumbore with the
-//     shader's edge convention, hit distance = length(dir*t) (RaytracerCS.hlsl:276,285,306-316),
-//     so for identity instances (all benchmark scenes) the closest hit equals the reference's bit
-//     for bit; only equal-distance ties may resolve to a different triangle.
-#include <chrono>
-#include <cstdlib>
-#include <cstring>
-
-#include "okrt_fast.h"
+// okrt_fast_trace.hip — the traversal kernels of the wavefront pipeline (okrt_fast_pipeline.hip has the overview):
+//   traceKernel         per-ray, persistent, "if-if" scheduling: every segment but the camera one
+//   tracePacketKernel   one wave per 8x8 pixel tile; FUSED = the whole camera segment (generate, trace, shade, append)
+//   fastKatKernel       one thread per ray, the known-answer probe
+#include "okrt_fast_internal.h"
 
 namespace okrt {
-
+namespace fastdetail {
 namespace {
-
-// Streaming accesses (ray queues, hit records, radiance slots: written once, read once, GBs per launch set) carry the
-// non-temporal hint so that they do not evict what IS reused — nodes, triangles, shading records, textures — from L2 and
-// the Infinity Cache.
-typedef float nt4_t __attribute__((ext_vector_type(4)));
-typedef float nt2_t __attribute__((ext_vector_type(2)));
-#ifdef OKRT_NO_NT
-__device__ __forceinline__ float4 ldStream(const float4* p) { return *p; }
-__device__ __forceinline__ float2 ldStream(const float2* p) { return *p; }
-__device__ __forceinline__ uint32_t ldStream(const uint32_t* p) { return *p; }
-__device__ __forceinline__ void stStream(float4* p, float4 v) { *p = v; }
-__device__ __forceinline__ void stStream(float2* p, float2 v) { *p = v; }
-__device__ __forceinline__ void stStream(uint32_t* p, uint32_t v) { *p = v; }
-#else
-__device__ __forceinline__ float4 ldStream(const float4* p) {
-    const nt4_t v = __builtin_nontemporal_load(reinterpret_cast<const nt4_t*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float2 ldStream(const float2* p) {
-    const nt2_t v = __builtin_nontemporal_load(reinterpret_cast<const nt2_t*>(p));
-    return make_float2(v.x, v.y);
-}
-__device__ __forceinline__ uint32_t ldStream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void stStream(float4* p, float4 v) {
-    const nt4_t w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<nt4_t*>(p));
-}
-__device__ __forceinline__ void stStream(float2* p, float2 v) {
-    const nt2_t w = {v.x, v.y};
-    __builtin_nontemporal_store(w, reinterpret_cast<nt2_t*>(p));
-}
-__device__ __forceinline__ void stStream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
-#endif
-
-constexpr int kTraceThreads = 256;
-#ifndef OKRT_LDS_STACK
-#define OKRT_LDS_STACK 10
-#endif
-#ifndef OKRT_PACKET_WAVES
-#define OKRT_PACKET_WAVES 5
-#endif
-#ifndef OKRT_TRACE_WAVES
-#define OKRT_TRACE_WAVES 7
-#endif
-constexpr int kLdsStack = OKRT_LDS_STACK;  // entries per lane kept in LDS
-constexpr int kRefillBelow = 40;     // refill idle lanes when fewer than this many lanes are active
-constexpr uint32_t kDone = kEmptyRef;
-constexpr uint32_t kShards = 8;      // queue shards = XCDs
-constexpr uint32_t kBatch = 64;      // rays a wave reserves per cursor atomic (sweep: 64 best with 5 blocks/CU)
-constexpr uint32_t kCursorStride = 32;  // words: one cursor per 128-byte line (device-scope atomics serialise per line)
-
-// A sharded queue: shard s owns positions [s*cap, s*cap + count(s)). Camera rays: count(s) follows
-// from `total`; queued rays: counts[] written by the shading kernel. cursors[] = next unreserved.
-struct ShardView {
-    uint32_t cap, total;
-    uint32_t batch, xcdAffinity, refillBelow;  // tunables (developer knobs: OKRT_FAST_BATCH / _AFFINITY / _REFILL)
-    uint32_t nodeMin, triMin;                  // a step block runs when at least this many lanes want it (OKRT_FAST_NODE_MIN / _TRI_MIN)
-    const uint32_t* counts;  // counts[s * kCursorStride]; nullptr for camera rays
-    uint32_t* cursors;       // cursors[s * kCursorStride]
-    __device__ uint32_t count(uint32_t s) const {
-        if (counts) return counts[s * kCursorStride];
-        const uint32_t lo = s * cap;
-        return total > lo ? min(total - lo, cap) : 0u;
-    }
-};
-
-struct RayQueue {        // SoA, capacity = owned pixels
-    float4* a;           // origin.xyz, dir.x
-    float4* b;           // dir.y, dir.z, seed (bits), framebuffer offset (bits)
-    float4* c;           // contribution.rgb, light.r
-    float2* d;           // light.g, light.b
-};
-struct HitBuffer {
-    float4* h;           // distance, bu, bv, hitIdx (bits)
-    uint32_t* tri;       // source triangle index (kInvalid for a sphere hit or a miss)
-};
-
-struct FastView {
-    const uint4* nodes;    // Node4Q as 4 x uint4
-    const float4* tris;    // Tri48 as 3 x float4
-    uint2* overflow;       // per-thread spill slab
-    uint32_t overflowCap;  // entries per thread
-};
-
-// Shading of one path segment from its hit record (RaytracerCS.hlsl:440-513): surface fetch, lights, environment on a
-// miss, BSDF sample. Updates ray / throughput / radiance / RNG state in place; returns true when the path continues.
-OKRT_DEV bool shadeSegment(const SceneView& s, const okrt_render_data& rd, Ray& ray, const Hit& h, uint32_t bounce, uint32_t lastBounce,
-                           V3& contribution, V3& light, uint32_t& seed, PathCounters& cnt) {
-    Surface sf = shadeFetch(s, ray, h, cnt);
-    addLights(s, rd, ray, sf, bounce, contribution, light, seed);
-    if (!sf.hit) {
-        light = fma3(sampleEnvironment(s, ray.direction, cnt), contribution, light);  // RaytracerCS.hlsl:489-493
-        return false;
-    }
-    scatter(sf, ray, contribution, light, seed);  // :495-513 (also on the last segment: emission is added here)
-    return bounce < lastBounce;
-}
-
-// primary ray index -> pixel (8x8 tiles, row-major over tiles)
-OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t& lrow) {
-    const uint32_t tilesX = (t.W + 7) >> 3;
-    const uint32_t tile = i >> 6, l = i & 63;
-    px = (tile % tilesX) * 8 + (l & 7);
-    lrow = (tile / tilesX) * 8 + (l >> 3);
-    return px < t.W && lrow < t.rows;
-}
-
-// Camera rays for every owned pixel, in tile order (position i <-> pixel by primaryPixel): origin, direction,
-// RNG state after the 4 camera draws, framebuffer offset. Padding positions (outside the image) get pix = kInvalid.
-// With `frames` > 1 the positions of frame f follow those of frame f-1 and pix addresses the frame's radiance slot.
-__global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileView tile, RayQueue q, uint32_t perFrame, uint32_t frames) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= perFrame * frames) return;
-    const uint32_t f = i / perFrame, ii = i - f * perFrame;
-    uint32_t px, lrow, seed = 0, pix = kInvalid;
-    Ray ray;
-    ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
-    if (primaryPixel(tile, ii, px, lrow)) {
-        ray = primaryRay(rd, rd.numAccumulationFrames + f, px, tile.globalRow(lrow), seed);
-        pix = f * (tile.rows * tile.W) + lrow * tile.W + px;
-    }
-    stStream(&q.a[i], make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x));
-    stStream(&q.b[i], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
-}
 
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
@@ -464,22 +309,6 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
 // distance of the first lane that enters, one shared stack of node references in LDS, no divergent control flow.
 // Each lane keeps its own closest hit with the same arithmetic as the per-ray kernel, so results agree bit for bit
 // (ties aside). Used for segment 0 only; bounce rays are incoherent and stay on the per-ray kernel.
-constexpr int kPacketStack = 128;  // shared entries per wave (>= 3 * tree depth + 4, checked on the host)
-
-// FUSED: the whole camera segment in this kernel — the rays are generated here instead of being read from queue 0, and
-// after the traversal the same wave shades its 64 hits and appends the surviving paths to queue 1. Against the
-// generate / trace / shade kernel triple this removes 136 bytes per pixel and frame of queue and hit-record traffic and
-// lets the issue-bound traversal of some waves overlap the memory-bound shading of others.
-struct FusedArgs {
-    uint32_t perFrame;        // queue positions per frame (tile padding included)
-    RayQueue qOut;            // queue 1
-    uint32_t* outCounts;      // its per-shard append counters
-    uint32_t lastBounce;
-    float4* accum;
-    uint32_t* result;
-    float4* radiance;
-    const okrt_render_data* rdDev;  // the same RenderData in device memory: read where it is used instead of being held in SGPRs across the tile loop
-};
 template <bool COUNT, bool FUSED>
 __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_PACKET_WAVES))) void tracePacketKernel(const uint4* __restrict__ nodes, const float4* __restrict__ tris,
                                                                   SceneView s, okrt_render_data rd, TileView tile, RayQueue q, HitBuffer hb,
@@ -741,192 +570,6 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
     }
 }
 
-// Shading of one path segment. FIRST: items are pixels (tile order), the camera ray is regenerated.
-// Finished paths (miss, or last segment) accumulate; the rest are compacted into `qOut`.
-template <bool FIRST, bool COUNT>
-__global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data rd, TileView tile, RayQueue qIn, HitBuffer hb,
-                                                  ShardView in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce,
-                                                  uint32_t lastBounce, float4* accum, uint32_t* result, float4* radiance,
-                                                  unsigned long long* counters) {
-    // positions are [shard][cap]; cap is a multiple of 256, so a block (and a wave) never straddles shards
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    const uint32_t shard = (blockIdx.x * 256) / in.cap;
-    const uint32_t total = shard * in.cap + in.count(shard);
-    PathCounters cnt = {};
-    bool alive = false;  // continues into the next segment
-    Ray ray;
-    V3 contribution = mk(1.f, 1.f, 1.f), light = mk(0.f, 0.f, 0.f);
-    uint32_t seed = 0, pix = 0;
-    bool valid = i < total;
-    if (valid) {
-        const float4 A = ldStream(&qIn.a[i]), B = ldStream(&qIn.b[i]);
-        ray.origin = mk(A.x, A.y, A.z);
-        ray.direction = mk(A.w, B.x, B.y);
-        seed = __float_as_uint(B.z);
-        pix = __float_as_uint(B.w);
-        valid = pix != kInvalid;
-        if (!FIRST) {  // camera rays start with throughput 1 and no radiance; later segments carry them
-            const float4 C = ldStream(&qIn.c[i]);
-            const float2 D = ldStream(&qIn.d[i]);
-            contribution = mk(C.x, C.y, C.z);
-            light = mk(C.w, D.x, D.y);
-        }
-    }
-    if (valid) {
-        float4 H = ldStream(&hb.h[i]);
-        Hit h;
-        h.distance = H.x;
-        h.bu = H.y;
-        h.bv = H.z;
-        h.hitIdx = __float_as_uint(H.w);
-        h.triIdx = ldStream(&hb.tri[i]);
-        h.hitType = h.triIdx != kInvalid ? 1u : 0u;
-        alive = shadeSegment(s, rd, ray, h, bounce, lastBounce, contribution, light, seed, cnt);
-        if (!alive) {
-            if (radiance) stStream(&radiance[pix], make_float4(light.x, light.y, light.z, 1.f));  // several frames in flight: added in frame order later
-            else writePixel(rd, light, 0, 0, accum, result, pix);
-        }
-    }
-    // ballot compaction of the surviving paths into the next queue: ranks inside the wave by ballot, waves inside
-    // the block through LDS, ONE atomic per block on the shard's counter (one per wave saturated the counter line)
-    __shared__ uint32_t sWaveCount[4], sBlockBase;
-    const unsigned long long m = __ballot(alive);
-    const uint32_t wave = threadIdx.x >> 6;
-    if (lane == 0) sWaveCount[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = sWaveCount[0] + sWaveCount[1] + sWaveCount[2] + sWaveCount[3];
-        sBlockBase = tot ? atomicAdd(&outCounts[shard * kCursorStride], tot) : 0u;  // survivors stay in their shard
-    }
-    __syncthreads();
-    if (alive) {
-        uint32_t before = 0;
-        for (uint32_t w = 0; w < wave; ++w) before += sWaveCount[w];
-        const uint32_t o = shard * in.cap + sBlockBase + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        stStream(&qOut.a[o], make_float4(ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x));
-        stStream(&qOut.b[o], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
-        stStream(&qOut.c[o], make_float4(contribution.x, contribution.y, contribution.z, light.x));
-        stStream(&qOut.d[o], make_float2(light.y, light.z));
-    }
-    if (COUNT && counters) {
-        uint32_t vals[5] = {(FIRST && valid) ? 1u : 0u, cnt.meshHits, cnt.sphereHits, cnt.texTaps, cnt.envTaps};
-        const int slot[5] = {0, 6, 7, 8, 9};
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            uint32_t v = vals[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
-        }
-    }
-}
-
-// Adds the radiance slots of `frames` frames to the accumulation IN FRAME ORDER and resolves with the last frame's
-// count: exactly what `frames` consecutive single-frame passes do (RaytracerCS.hlsl:526-536).
-__global__ __launch_bounds__(256) void accumulateKernel(okrt_render_data rd, uint32_t pixels, uint32_t frames, const float4* radiance,
-                                                       float4* accum, uint32_t* result) {
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= pixels) return;
-    float4 a = accum[p];
-    for (uint32_t f = 0; f < frames; ++f) {
-        const float4 r = ldStream(&radiance[(size_t)f * pixels + p]);
-        a.x += r.x; a.y += r.y; a.z += r.z; a.w += 1.f;
-    }
-    accum[p] = a;
-    const float n = (float)(rd.numAccumulationFrames + frames - 1u);
-    result[p] = toUnorm8(a.x / n) | (toUnorm8(a.y / n) << 8) | (toUnorm8(a.z / n) << 16) | (toUnorm8(a.w / n) << 24);
-}
-
-template <class T>
-bool devAlloc(T** p, size_t n, std::string& err) {
-    if (*p) hipFree(*p);
-    *p = nullptr;
-    if (!n) return true;
-    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
-    if (e != hipSuccess) {
-        err = std::string("hipMalloc: ") + hipGetErrorString(e);
-        return false;
-    }
-    return true;
-}
-
-}  // namespace
-
-constexpr uint32_t kMaxSegments = 66;                       // max_bounces <= 64
-constexpr uint32_t kCursorBase = kMaxSegments * kShards * kCursorStride;
-constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorStride;
-
-struct FastScene {
-    DeviceArray<uint4> nodes;   // 4 x uint4 per Node4Q
-    DeviceArray<float4> tris;   // 3 x float4 per Tri48
-    uint32_t numNodes = 0, numTris = 0, maxDepth = 0;
-    bool allIdentity = true;
-    DeviceBuilder* builder = nullptr;  // device-side build scratch (okrt_fast_build_device.hip), made on first use
-    FastBuildInfo info = {};
-    // pipeline state, sized lazily for the tile
-    size_t capacity = 0;
-    RayQueue q[2] = {};
-    HitBuffer hb = {};
-    uint32_t* counts = nullptr;  // per segment b, shard s: count at (b*kShards + s)*kCursorStride, cursor at kCursorBase + the same
-                                 // (every counter on its own 128-byte line: device-scope atomics serialise per line)
-    uint2* overflow = nullptr;
-    uint32_t overflowCap = 0;
-    int traceBlocks = 0, cus = 0;
-    size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
-    okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
-    float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
-    size_t radianceCap = 0;
-};
-
-bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& tables, uint32_t builder, hipStream_t stream, std::string& err) {
-    if (!*scene) *scene = new FastScene();
-    FastScene& fs = **scene;
-    const auto t0 = std::chrono::steady_clock::now();
-    float deviceMs = 0.f;
-    if (builder == 1u) {
-        if (!fs.builder) fs.builder = deviceBuilderCreate();
-        FastDeviceResult r{fs.nodes, fs.tris};
-        if (!buildFastDevice(*fs.builder, in, tables, stream, r, err)) return false;
-        fs.numNodes = r.numNodes;
-        fs.numTris = r.numTris;
-        fs.maxDepth = r.maxDepth;
-        fs.allIdentity = r.allIdentity;
-        deviceMs = r.buildMs;
-    } else {
-        FastHostScene host;
-        buildFastHost(in, host);
-        fs.numNodes = (uint32_t)host.nodes.size();
-        fs.numTris = (uint32_t)host.tris.size();
-        fs.maxDepth = host.maxDepth;
-        fs.allIdentity = host.allIdentity;
-        if (!fs.nodes.need(host.nodes.size() * 4, err)) return false;
-        if (!fs.tris.need(std::max<size_t>(host.tris.size(), 1) * 3, err)) return false;
-        hipError_t e = hipMemcpyAsync(fs.nodes.p, host.nodes.data(), host.nodes.size() * sizeof(Node4Q), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess && !host.tris.empty())
-            e = hipMemcpyAsync(fs.tris.p, host.tris.data(), host.tris.size() * sizeof(Tri48), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `host` dies at return
-        if (e != hipSuccess) {
-            err = std::string("upload: ") + hipGetErrorString(e);
-            return false;
-        }
-    }
-    fs.info = {builder, fs.numNodes, fs.numTris, fs.maxDepth, deviceMs,
-               std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()};
-    // spill slab: a visit pushes at most 3 entries, so 3*depth bounds the stack
-    int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    fs.cus = cus;
-    fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : OKRT_TRACE_WAVES);
-    uint32_t need = 3 * fs.maxDepth + 4;
-    uint32_t cap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;
-    if (cap != fs.overflowCap || !fs.overflow) {
-        if (!devAlloc(&fs.overflow, (size_t)fs.traceBlocks * kTraceThreads * cap, err)) return false;
-        fs.overflowCap = cap;
-    }
-    if (!fs.counts && !devAlloc(&fs.counts, kCountWords, err)) return false;
-    return true;
-}
-
 // Known-answer probe (okrt_debug_kat, CLOSEST_HIT_FAST): one thread per ray walks the structure with a private stack —
 // the same node decoding, slab arithmetic, triangle test and hit-distance formula as the trace kernels, none of their
 // scheduling — so tests can compare the structure's closest hit with the oracle's ray by ray.
@@ -1001,174 +644,29 @@ __global__ __launch_bounds__(64) void fastKatKernel(const uint4* __restrict__ no
     o[4] = __uint_as_float(hitTri);
 }
 
-bool fastKat(const FastScene* fs, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, hipStream_t stream,
-             std::string& err) {
-    if (!fs || !fs->nodes.p) {
-        err = "no structure built yet";
-        return false;
-    }
-    if (4 * fs->maxDepth + 4 > 256u) {
-        err = "tree too deep for the probe's private stack";
-        return false;
-    }
-    if (n) hipLaunchKernelGGL(fastKatKernel, dim3((n + 63) / 64), dim3(64), 0, stream, fs->nodes.p, fs->tris.p, s, n, in, inFloats, out, outFloats);
-    return true;
+}  // namespace
+
+void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
+                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals) {
+    const dim3 tb(kTraceThreads);
+    if (count) hipLaunchKernelGGL((traceKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+    else hipLaunchKernelGGL((traceKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
 }
 
-void fastSetQueueBudget(FastScene** scene, size_t bytes) {
-    if (!*scene) *scene = new FastScene();
-    (*scene)->queueBudgetBytes = bytes;
+void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,
+                  const okrt_render_data& rd, const TileView& tile, RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames,
+                  unsigned long long* counters, unsigned long long* rayTotals, const FusedArgs& fa) {
+    const dim3 tb(kTraceThreads);
+    if (count && fused) hipLaunchKernelGGL((tracePacketKernel<true, true>), grid, tb, 0, stream, nodes, tris, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, fa);
+    else if (fused) hipLaunchKernelGGL((tracePacketKernel<false, true>), grid, tb, 0, stream, nodes, tris, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, fa);
+    else if (count) hipLaunchKernelGGL((tracePacketKernel<true, false>), grid, tb, 0, stream, nodes, tris, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, fa);
+    else hipLaunchKernelGGL((tracePacketKernel<false, false>), grid, tb, 0, stream, nodes, tris, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, fa);
 }
 
-void fastBuildInfo(const FastScene* fs, FastBuildInfo* info) {
-    if (fs) *info = fs->info;
-    else std::memset(info, 0, sizeof(*info));
+void launchFastKat(hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats,
+                   float* out, uint32_t outFloats) {
+    if (n) hipLaunchKernelGGL(fastKatKernel, dim3((n + 63) / 64), dim3(64), 0, stream, nodes, tris, s, n, in, inFloats, out, outFloats);
 }
 
-bool fastReadStructure(const FastScene* fs, void* nodes, uint32_t nodeCapacity, void* tris, uint32_t triCapacity, hipStream_t stream, std::string& err) {
-    if (!fs) {
-        err = "no structure built yet";
-        return false;
-    }
-    if ((nodes && nodeCapacity < fs->numNodes) || (tris && triCapacity < fs->numTris)) {
-        err = "capacity too small";
-        return false;
-    }
-    hipError_t e = hipSuccess;
-    if (nodes && fs->numNodes) e = hipMemcpyAsync(nodes, fs->nodes.p, (size_t)fs->numNodes * sizeof(Node4Q), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess && tris && fs->numTris) e = hipMemcpyAsync(tris, fs->tris.p, (size_t)fs->numTris * sizeof(Tri48), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) {
-        err = std::string("read structure: ") + hipGetErrorString(e);
-        return false;
-    }
-    return true;
-}
-
-void fastDestroy(FastScene* fs) {
-    if (!fs) return;
-    fs->nodes.release();
-    fs->tris.release();
-    if (fs->builder) deviceBuilderDestroy(fs->builder);
-    for (void* p : {(void*)fs->rdDev, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
-        if (p) hipFree(p);
-    for (RayQueue& q : fs->q)
-        for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
-            if (p) hipFree(p);
-    delete fs;
-}
-
-bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
-                unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
-                std::string& err) {
-    const uint32_t perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
-    if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)perFrame * frames > 0x7FFFFFFFull) {
-        err = "frames per launch out of range";
-        return false;
-    }
-    const uint32_t total = perFrame * frames;
-    const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
-    const size_t items = (size_t)cap * kShards;
-    // per item: two ray queues (16+16+16+8 B each) + hit record (16+4 B); per pixel and frame: a 16-byte radiance slot
-    const size_t needBytes = items * (2 * 56 + 20) + (frames > 1 ? (size_t)t.rows * t.W * frames * 16 : 0);
-    if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
-        err = "launch set exceeds the queue memory budget";
-        return false;
-    }
-    if (items > fs.capacity) {
-        hipStreamSynchronize(stream);
-        fs.capacity = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
-        for (RayQueue& q : fs.q)
-            if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return false;
-        if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return false;
-        fs.capacity = items;
-    }
-    const size_t pixels = (size_t)t.rows * t.W;
-    float4* radiance = nullptr;
-    if (frames > 1) {
-        if (pixels * frames > fs.radianceCap) {
-            hipStreamSynchronize(stream);
-            fs.radianceCap = 0;
-            if (!devAlloc(&fs.radiance, pixels * frames, err)) return false;
-            fs.radianceCap = pixels * frames;
-        }
-        radiance = fs.radiance;
-    }
-    const uint32_t lastBounce = s.maxBounces;
-    if (lastBounce + 2 > kMaxSegments) {
-        err = "max_bounces too large for the fast pipeline";
-        return false;
-    }
-    hipMemsetAsync(fs.counts, 0, (size_t)kCountWords * sizeof(uint32_t), stream);
-    FastView fv{fs.nodes.p, fs.tris.p, fs.overflow, fs.overflowCap};
-    const dim3 tb(kTraceThreads), tg(fs.traceBlocks);
-    const dim3 sg((unsigned)(items / 256));
-    const bool cnt = counters != nullptr;
-    int ev = 0;
-    auto mark = [&]() { if (events) hipEventRecord(events[ev++], stream); };
-    static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
-    static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
-    static const uint32_t envNodeMin = getenv("OKRT_FAST_NODE_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_NODE_MIN")) : 32u;
-    static const uint32_t envTriMin = getenv("OKRT_FAST_TRI_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_TRI_MIN")) : 24u;
-    static const uint32_t envRefill = getenv("OKRT_FAST_REFILL") ? (uint32_t)atoi(getenv("OKRT_FAST_REFILL")) : (uint32_t)kRefillBelow;
-    auto shards = [&](uint32_t b, bool camera) {
-        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, envNodeMin, envTriMin, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
-                         fs.counts + kCursorBase + b * kShards * kCursorStride};
-    };
-    mark();
-    static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
-    static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
-    const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
-    static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
-    const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
-    if (!fs.rdDev && !devAlloc(&fs.rdDev, 1, err)) return false;
-    hipMemcpyAsync(fs.rdDev, &rd, sizeof(rd), hipMemcpyHostToDevice, stream);  // stream order: the previous launch set has read its copy
-    const FusedArgs fa{perFrame, fs.q[1], fs.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, fs.rdDev};
-    if (packet && envFused) {
-        // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
-        if (cnt)
-            hipLaunchKernelGGL((tracePacketKernel<true, true>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
-        else
-            hipLaunchKernelGGL((tracePacketKernel<false, true>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
-        mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
-    } else {
-        // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
-        hipLaunchKernelGGL(generateKernel, sg, dim3(256), 0, stream, rd, t, fs.q[0], perFrame, frames);
-        if (packet && cnt)
-            hipLaunchKernelGGL((tracePacketKernel<true, false>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
-        else if (packet)
-            hipLaunchKernelGGL((tracePacketKernel<false, false>), pg, tb, 0, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
-        else if (cnt)
-            hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
-        else
-            hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
-        mark();
-        if (cnt)
-            hipLaunchKernelGGL((shadeKernel<true, true>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
-        else
-            hipLaunchKernelGGL((shadeKernel<true, false>), sg, dim3(256), 0, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result, radiance, counters);
-    }
-    if (lastBounce == 0 && radiance)
-        hipLaunchKernelGGL(accumulateKernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, rd, (uint32_t)pixels, frames, radiance, accum, result);
-    mark();
-    // segments 1..lastBounce: queue b lives in q[b & 1]
-    for (uint32_t b = 1; b <= lastBounce; ++b) {
-        RayQueue& qin = fs.q[b & 1];
-        RayQueue& qout = fs.q[(b + 1) & 1];
-        if (cnt)
-            hipLaunchKernelGGL((traceKernel<true>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals);
-        else
-            hipLaunchKernelGGL((traceKernel<false>), tg, tb, 0, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals);
-        mark();
-        if (cnt)
-            hipLaunchKernelGGL((shadeKernel<false, true>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, radiance, counters);
-        else
-            hipLaunchKernelGGL((shadeKernel<false, false>), sg, dim3(256), 0, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum, result, radiance, counters);
-        if (b == lastBounce && radiance)
-            hipLaunchKernelGGL(accumulateKernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, rd, (uint32_t)pixels, frames, radiance, accum, result);
-        mark();
-    }
-    return true;
-}
-
+}  // namespace fastdetail
 }  // namespace okrt

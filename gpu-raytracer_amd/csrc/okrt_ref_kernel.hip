@@ -6,7 +6,7 @@
 // triangle of a leaf. Its purpose is parity and accounting, not speed: visit order, tie-breaking
 // and the bbCheckCount / triCheckCount debug counters are those of the reference, which makes its
 // counters the layout-independent "algorithmic bytes" numerator of the roofline.
-// The fast traversal (okrt_fast_kernel.hip) is checked against this kernel and the CPU oracle.
+// The fast traversal (okrt_fast_trace.hip) is checked against this kernel and the CPU oracle.
 //
 // Launch shape: 256-thread blocks = 4 wave64, each wave an 8x8 pixel tile (the reference's 16x9
 // groups are 2.25 waves; quirk Q16), blocks cover 16x16 pixels; every pixel of the owned rows is
