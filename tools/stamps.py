@@ -1,4 +1,4 @@
-"""Diagnostic: where do the trace kernels' wave-cycles go? (needs libokrt_stamps.so built with -DOKRT_STAMPS)"""
+"""Diagnostic: where do the trace kernels' wave-cycles go? (needs libokrt_stamps.so: tools/build_variant.sh stamps okrt_fast_trace.hip -DOKRT_STAMPS)"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["OKRT_LIBRARY"] = "gpu-raytracer_amd/libokrt_stamps.so"
