@@ -99,6 +99,11 @@ struct FastDeviceResult {
     bool allIdentity = true;
     float buildMs = 0.f;         // device timeline, first kernel to last
 };
+// Upper levels for the device builder (okrt_fast_build.cpp): binned SAH over n cluster boxes ({min[3], max[3]} each)
+// weighted by their triangle counts. Children < n are clusters, others n + index into `out`; returns the root reference.
+struct TopNode { float mn[3]; uint32_t left; float mx[3]; uint32_t right; uint32_t count; };
+uint32_t buildTopSAH(const float* boxes6, const uint32_t* weights, uint32_t n, std::vector<TopNode>& out);
+
 struct DeviceBuilder;
 DeviceBuilder* deviceBuilderCreate();
 void deviceBuilderDestroy(DeviceBuilder*);

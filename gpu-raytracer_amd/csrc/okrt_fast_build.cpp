@@ -374,6 +374,100 @@ void buildFastHost(const FastInputs& in, FastHostScene& out) {
     out.maxDepth = e.maxDepth;
 }
 
+// ---- top of the tree for the device builder ---------------------------------------------------------------------------
+// PLOC clusters bottom-up inside a Morton window and never sees the large occluders of an architectural scene; a
+// top-down SAH does. The device builder therefore stops clustering at a few thousand clusters and hands their boxes
+// and triangle counts to this routine, which builds the upper levels by binned SAH weighted with the counts.
+namespace {
+struct TopItem { Box box; float c[3]; uint32_t weight, id; };
+uint32_t buildTopRange(std::vector<TopItem>& items, uint32_t lo, uint32_t hi, uint32_t n, std::vector<TopNode>& out) {
+    if (hi - lo == 1) return items[lo].id;  // a cluster
+    Box bb, cb;
+    uint32_t total = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        bb.grow(items[i].box);
+        cb.grow(items[i].c);
+        total += items[i].weight;
+    }
+    int bestAxis = -1, bestBin = -1;
+    float bestCost = FLT_MAX;
+    for (int axis = 0; axis < 3; ++axis) {
+        const float cmin = cb.mn[axis], cext = cb.mx[axis] - cb.mn[axis];
+        if (!(cext > 0.f)) continue;
+        const float scale = kBins / cext;
+        Box binBox[kBins];
+        uint32_t binW[kBins] = {}, binN[kBins] = {};
+        for (uint32_t i = lo; i < hi; ++i) {
+            const int b = std::min(kBins - 1, std::max(0, (int)((items[i].c[axis] - cmin) * scale)));
+            binW[b] += items[i].weight;
+            binN[b]++;
+            binBox[b].grow(items[i].box);
+        }
+        float rightArea[kBins];
+        uint32_t rightW[kBins], rightN[kBins];
+        Box acc;
+        uint32_t w = 0, c = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+            acc.grow(binBox[b]);
+            w += binW[b];
+            c += binN[b];
+            rightArea[b] = acc.area();
+            rightW[b] = w;
+            rightN[b] = c;
+        }
+        Box accL;
+        uint32_t wl = 0, cl = 0;
+        for (int b = 0; b < kBins - 1; ++b) {
+            accL.grow(binBox[b]);
+            wl += binW[b];
+            cl += binN[b];
+            if (!cl || !rightN[b + 1]) continue;
+            const float cost = accL.area() * (float)wl + rightArea[b + 1] * (float)rightW[b + 1];
+            if (cost < bestCost) {
+                bestCost = cost;
+                bestAxis = axis;
+                bestBin = b;
+            }
+        }
+    }
+    uint32_t mid = lo + (hi - lo) / 2;
+    if (bestAxis >= 0) {
+        const float cmin = cb.mn[bestAxis], scale = kBins / (cb.mx[bestAxis] - cb.mn[bestAxis]);
+        auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const TopItem& t) {
+            return std::min(kBins - 1, std::max(0, (int)((t.c[bestAxis] - cmin) * scale))) <= bestBin;
+        });
+        const uint32_t m = (uint32_t)(it - items.begin());
+        if (m != lo && m != hi) mid = m;
+    }
+    const uint32_t self = (uint32_t)out.size();
+    out.emplace_back();
+    const uint32_t l = buildTopRange(items, lo, mid, n, out), r = buildTopRange(items, mid, hi, n, out);
+    TopNode& t = out[self];
+    for (int k = 0; k < 3; ++k) { t.mn[k] = bb.mn[k]; t.mx[k] = bb.mx[k]; }
+    t.left = l;
+    t.right = r;
+    t.count = total;
+    return n + self;
+}
+}  // namespace
+
+uint32_t buildTopSAH(const float* boxes6, const uint32_t* weights, uint32_t n, std::vector<TopNode>& out) {
+    std::vector<TopItem> items(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        TopItem& t = items[i];
+        for (int k = 0; k < 3; ++k) {
+            t.box.mn[k] = boxes6[6 * i + k];
+            t.box.mx[k] = boxes6[6 * i + 3 + k];
+            t.c[k] = 0.5f * t.box.mn[k] + 0.5f * t.box.mx[k];
+        }
+        t.weight = weights[i];
+        t.id = i;
+    }
+    out.clear();
+    out.reserve(n);
+    return buildTopRange(items, 0, n, n, out);
+}
+
 }  // namespace okrt
 
 // ---- host-side check of the structure (no GPU): used by tests/test_fast_structure.py ----------------

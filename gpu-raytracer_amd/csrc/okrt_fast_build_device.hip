@@ -285,6 +285,7 @@ __global__ __launch_bounds__(kBT) void mergeKernel(Node2D* __restrict__ nodes, u
 // few clusters left an iteration still merges only a fraction of them (45 of the 58 iterations of a 262 k triangle
 // scene run below 1000 clusters), and each global iteration costs five launches and a host read-back.
 constexpr int kTailClusters = 1024;
+constexpr uint32_t kTopClusters = 1024;  // clusters handed to the host's SAH for the upper levels (0 = PLOC all the way)
 __global__ __launch_bounds__(kTailClusters) void plocTailKernel(Node2D* __restrict__ nodes, uint32_t* __restrict__ cnt, uint32_t* __restrict__ clusters,
                                                                 uint32_t n, Counters* __restrict__ counters, int kRadius) {
     __shared__ float4 sLo[kTailClusters], sHi[kTailClusters];
@@ -379,6 +380,20 @@ __global__ __launch_bounds__(kTailClusters) void plocTailKernel(Node2D* __restri
         clusters[0] = id;
         counters[kCntNode2].v[0] = nodeBase + created;
     }
+}
+
+// boxes and triangle counts of the remaining clusters, for the host's SAH over the upper levels (buildTopSAH)
+__global__ __launch_bounds__(kBT) void gatherClustersKernel(const Node2D* __restrict__ nodes, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ clusters,
+                                                            uint32_t n, float* __restrict__ boxes6, uint32_t* __restrict__ weights) {
+    const uint32_t i = blockIdx.x * kBT + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = clusters[i];
+    const Node2D& nd = nodes[id];
+    for (int k = 0; k < 3; ++k) {
+        boxes6[6 * i + k] = nd.mn[k];
+        boxes6[6 * i + 3 + k] = nd.mx[k];
+    }
+    weights[i] = cnt[id];
 }
 
 // ---- collapse --------------------------------------------------------------------------------------
@@ -573,16 +588,21 @@ struct DeviceBuilder {
     DeviceArray<uint32_t> cnt, valsA, valsB, nn, next;
     DeviceArray<unsigned long long> keysA, keysB;
     DeviceArray<uint8_t> keep, tmp;
+    DeviceArray<float> topBoxes;
     DeviceArray<uint2> queueA, queueB;
     DeviceArray<Counters> counters;
     uint32_t* pinned = nullptr;  // host-visible read-back words
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per mesh BVH root: the leaf triangle ranges (merged); valid until t0/t2 change
     std::unordered_map<uint32_t, std::vector<std::pair<uint32_t, uint32_t>>> leafRanges;
+    // staging for the SAH-built upper levels
+    std::vector<float> hostBoxes;
+    std::vector<uint32_t> hostWeights, hostClusters, hostCounts;
+    std::vector<Node2D> hostNodes;
     ~DeviceBuilder() {
         ranges.release(); prims.release(); cent.release(); nodes.release(); cnt.release(); valsA.release(); valsB.release();
         nn.release(); next.release(); keysA.release(); keysB.release(); keep.release(); tmp.release(); queueA.release();
-        queueB.release(); counters.release();
+        queueB.release(); counters.release(); topBoxes.release();
         if (pinned) hipHostFree(pinned);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
@@ -705,7 +725,11 @@ bool buildFastDevice(DeviceBuilder& B, const FastInputs& in, const FastDeviceTab
     static const int radius = std::min(std::max(getenv("OKRT_BUILD_RADIUS") ? atoi(getenv("OKRT_BUILD_RADIUS")) : kRadius, 1), kMaxRadius);
     uint32_t* cur = B.valsB.p;
     uint32_t* alt = B.valsA.p;
-    for (int iter = 0; n > (uint32_t)kTailClusters; ++iter) {
+    // clustering stops at kTopClusters clusters: the levels above them are built top-down by SAH on the host (a few
+    // thousand boxes, < 1 ms) — PLOC's Morton window cannot see the large occluders that matter up there
+    static const uint32_t topClusters = getenv("OKRT_BUILD_TOP") ? (uint32_t)atoi(getenv("OKRT_BUILD_TOP")) : kTopClusters;
+    const uint32_t stopAt = std::max<uint32_t>(topClusters, (uint32_t)kTailClusters);
+    for (int iter = 0; n > stopAt; ++iter) {
         if (iter > 4096) {
             err = "device build: clustering did not converge";
             return false;
@@ -725,10 +749,42 @@ bool buildFastDevice(DeviceBuilder& B, const FastInputs& in, const FastDeviceTab
         n = m;
         std::swap(cur, alt);
     }
-    if (n > 1) plocTailKernel<<<1, kTailClusters, 0, stream>>>(B.nodes.p, B.cnt.p, cur, n, B.counters.p, radius);
-    OKRT_BUILD_HIP(hipMemcpyAsync(B.pinned, cur, 4, hipMemcpyDeviceToHost, stream));
-    OKRT_BUILD_HIP(hipStreamSynchronize(stream));
-    const uint32_t root = B.pinned[0];
+    uint32_t root = 0;
+    if (topClusters && n > 1) {
+        if (!B.topBoxes.need((size_t)n * 6, err, true)) return false;
+        float* dBoxes = B.topBoxes.p;  // (B.nn is free now: it takes the counts)
+        gatherClustersKernel<<<(n + kBT - 1) / kBT, kBT, 0, stream>>>(B.nodes.p, B.cnt.p, cur, n, dBoxes, B.nn.p);
+        B.hostBoxes.resize((size_t)n * 6);
+        B.hostWeights.resize(n);
+        B.hostClusters.resize(n);
+        OKRT_BUILD_HIP(hipMemcpyAsync(B.hostBoxes.data(), dBoxes, (size_t)n * 24, hipMemcpyDeviceToHost, stream));
+        OKRT_BUILD_HIP(hipMemcpyAsync(B.hostWeights.data(), B.nn.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        OKRT_BUILD_HIP(hipMemcpyAsync(B.hostClusters.data(), cur, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        OKRT_BUILD_HIP(hipMemcpyAsync(B.pinned, &B.counters.p[kCntNode2].v[0], 4, hipMemcpyDeviceToHost, stream));
+        OKRT_BUILD_HIP(hipStreamSynchronize(stream));
+        const uint32_t nodeBase = B.pinned[0];
+        std::vector<TopNode> top;
+        const uint32_t topRoot = buildTopSAH(B.hostBoxes.data(), B.hostWeights.data(), n, top);
+        auto ref = [&](uint32_t r) { return r < n ? B.hostClusters[r] : nodeBase + (r - n); };
+        B.hostNodes.resize(top.size());
+        B.hostCounts.resize(top.size());
+        for (size_t k = 0; k < top.size(); ++k) {
+            Node2D& nd = B.hostNodes[k];
+            for (int a = 0; a < 3; ++a) { nd.mn[a] = top[k].mn[a]; nd.mx[a] = top[k].mx[a]; }
+            nd.left = ref(top[k].left);
+            nd.right = ref(top[k].right);
+            B.hostCounts[k] = top[k].count;
+        }
+        OKRT_BUILD_HIP(hipMemcpyAsync(B.nodes.p + nodeBase, B.hostNodes.data(), top.size() * sizeof(Node2D), hipMemcpyHostToDevice, stream));
+        OKRT_BUILD_HIP(hipMemcpyAsync(B.cnt.p + nodeBase, B.hostCounts.data(), top.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        OKRT_BUILD_HIP(hipStreamSynchronize(stream));  // the staging vectors may be reused by the next build
+        root = ref(topRoot);
+    } else {
+        if (n > 1) plocTailKernel<<<1, kTailClusters, 0, stream>>>(B.nodes.p, B.cnt.p, cur, n, B.counters.p, radius);
+        OKRT_BUILD_HIP(hipMemcpyAsync(B.pinned, cur, 4, hipMemcpyDeviceToHost, stream));
+        OKRT_BUILD_HIP(hipStreamSynchronize(stream));
+        root = B.pinned[0];
+    }
 
     // ---- collapse ----------------------------------------------------------------------------------------
     OKRT_BUILD_HIP(hipMemcpyAsync(B.pinned + 2, &B.cnt.p[root], 4, hipMemcpyDeviceToHost, stream));
