@@ -14,6 +14,9 @@
 //          left and right in Morton order for the partner with the smallest union area, mutual pairs merge, the
 //          cluster array is compacted (rocPRIM select) — repeated until one cluster is left. Quality is that of
 //          a SAH build, cost is ~3 sweeps over the input.
+//   top    clustering stops at ~1024 clusters; the levels above them are built top-down by binned SAH on the host
+//          (buildTopSAH, okrt_fast_build.cpp: < 1 ms) and uploaded as ordinary BVH2 nodes — a Morton window cannot see
+//          the large occluders that decide the upper levels
 //   collapse  level by level: each thread turns one BVH2 subtree root into a Node4Q by opening the largest inner
 //          child until four, quantises the child boxes (the host's makeNode4Q arithmetic), emits leaves of <= 4
 //          triangles as Tri48. Slots are handed out by wave-aggregated atomics (one atomic per wave and counter:
