@@ -11,7 +11,7 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 
-OKRT_ABI_VERSION = 1
+OKRT_ABI_VERSION = 2
 
 # okrt_table slots = the reference's t-registers (ShaderResourceRegisters.h:9-21)
 TABLE_TRI_POS, TABLE_TRI_INFO, TABLE_BVH = 0, 1, 2
@@ -22,6 +22,7 @@ TABLE_STRIDE = {0: 36, 1: 132, 2: 36, 5: 48, 6: 84, 7: 232, 8: 32, 9: 32, 10: 48
 OPT_TRAVERSAL, OPT_MAX_BOUNCES, OPT_COUNTERS, OPT_TIMING, OPT_BUILDER, OPT_DEFER, OPT_QUEUE_MEMORY_MB = 0, 1, 2, 3, 4, 5, 6
 BUILDER_HOST, BUILDER_DEVICE = 0, 1
 TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
+BUILD_FLAG_SCALED_INSTANCES, BUILD_FLAG_SHRUNK_INSTANCES = 1, 2
 
 
 class RenderData(C.Structure):
@@ -96,6 +97,7 @@ PRODUCT_ONLY = {
 }
 KAT_PCG_HASH, KAT_RANDOM_FLOAT, KAT_RAY_SPHERE, KAT_RAY_TRIANGLE, KAT_RAY_AABB, KAT_REFRACT, KAT_SAMPLE_TEXTURE, KAT_SAMPLE_ENV, KAT_CLOSEST_HIT, KAT_CLOSEST_HIT_FAST = range(10)
 KAT_RANDOM_VECTOR, KAT_REFLECTANCE, KAT_REFLECT_DIRECTION, KAT_TRANSPARENCY_BOUNCE, KAT_PRIMARY_RAY = range(10, 15)
+KAT_SEGMENT_RAY = 15
 HEADER_SYMBOLS = ["okrt_" + n for n in list(SIGNATURES) + list(PRODUCT_ONLY)]
 
 

@@ -195,6 +195,42 @@ okrt_status validateTables(okrt_ctx* c) {
     return OKRT_OK;
 }
 
+// OKRT_BUILD_FLAG_*: singular values of the linear part of every instance matrix in t7 (eigenvalues of A^T A, closed
+// form for a symmetric 3x3), against 1 with a tolerance that float rotations stay inside.
+uint32_t instanceFlags(const okrt_ctx* c) {
+    const Table& me = c->tables[OKRT_TABLE_MESH];
+    const MeshRec* meshes = (const MeshRec*)me.host.data();
+    uint32_t flags = 0;
+    for (uint32_t i = 0; i < me.count; ++i) {
+        const float* m = meshes[i].M;
+        const double A[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
+        double S[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) S[r][q] = A[0][r] * A[0][q] + A[1][r] * A[1][q] + A[2][r] * A[2][q];
+        const double p1 = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
+        const double tr = (S[0][0] + S[1][1] + S[2][2]) / 3.0;
+        double lo, hi;
+        if (p1 < 1e-24) {
+            lo = std::min(S[0][0], std::min(S[1][1], S[2][2]));
+            hi = std::max(S[0][0], std::max(S[1][1], S[2][2]));
+        } else {
+            const double p2 = (S[0][0] - tr) * (S[0][0] - tr) + (S[1][1] - tr) * (S[1][1] - tr) + (S[2][2] - tr) * (S[2][2] - tr) + 2.0 * p1;
+            const double p = std::sqrt(p2 / 6.0);
+            double B[3][3];
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) B[r][q] = (S[r][q] - (r == q ? tr : 0.0)) / p;
+            const double det = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                               B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+            const double phi = std::acos(std::min(1.0, std::max(-1.0, det / 2.0))) / 3.0;
+            hi = tr + 2.0 * p * std::cos(phi);
+            lo = tr + 2.0 * p * std::cos(phi + 2.0943951023931953);
+        }
+        if (!(lo > 1.0 - 1e-4 && hi < 1.0 + 1e-4)) flags |= OKRT_BUILD_FLAG_SCALED_INSTANCES;  // also catches NaN
+        if (!(lo > 1.0 - 1e-4)) flags |= OKRT_BUILD_FLAG_SHRUNK_INSTANCES;
+    }
+    return flags;
+}
+
 SceneView makeView(const okrt_ctx* c) {
     SceneView s{};
     s.triPos = (const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].dev.ptr;
@@ -545,6 +581,7 @@ okrt_status okrt_get_build_info(okrt_ctx* c, okrt_build_info* out) {
     out->max_depth = bi.maxDepth;
     out->device_ms = bi.deviceMs;
     out->wall_ms = bi.wallMs;
+    out->flags = instanceFlags(c);
     return OKRT_OK;
 }
 
@@ -785,12 +822,12 @@ okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames
 }
 
 okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats) {
-    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_PRIMARY_RAY) return OKRT_ERR_INVALID_ARG;
-    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7, 1, 2, 8, 8, 62}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5, 4, 1, 4, 4, 7};
+    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_SEGMENT_RAY) return OKRT_ERR_INVALID_ARG;
+    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7, 1, 2, 8, 8, 62, 63}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5, 4, 1, 4, 4, 7, 8};
     if (in_floats < needIn[op] || out_floats < needOut[op]) return fail(c, OKRT_ERR_INVALID_ARG, "kat: record too short for this probe");
     OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
-    if (op == OKRT_KAT_CLOSEST_HIT || op == OKRT_KAT_CLOSEST_HIT_FAST) {  // walks the uploaded tables: they must be consistent
+    if (op == OKRT_KAT_CLOSEST_HIT || op == OKRT_KAT_CLOSEST_HIT_FAST || op == OKRT_KAT_SEGMENT_RAY) {  // walks the uploaded tables: they must be consistent
         okrt_status vs = ensureTables(c);
         if (vs == OKRT_OK && op == OKRT_KAT_CLOSEST_HIT_FAST) vs = ensureFast(c);
         if (vs != OKRT_OK) return vs;

@@ -304,6 +304,29 @@ __global__ __launch_bounds__(256) void katKernel(SceneView s, uint32_t op, uint3
             o[5] = __uint_as_float(h.triIdx);
             break;
         }
+        case OKRT_KAT_SEGMENT_RAY: {  // px(bits) py(bits) k(bits) RenderData[60] -> alive?, origin[3], direction[3], seed
+            // the ray that enters path segment k of this pixel, following the reference-order path (k = 0: the camera ray)
+            okrt_render_data rd;
+            float* rf = reinterpret_cast<float*>(&rd);
+            for (int j = 0; j < 60; ++j) rf[j] = a[3 + j];
+            const uint32_t k = __float_as_uint(a[2]);
+            uint32_t seed = 0;
+            Ray r = primaryRay(rd, __float_as_uint(a[0]), __float_as_uint(a[1]), seed);
+            V3 light = mk(0.f, 0.f, 0.f), contribution = mk(1.f, 1.f, 1.f);
+            uint32_t bb = 0, tri = 0, alive = 1u;
+            for (uint32_t i = 0; i < k && alive; i++) {  // RaytracerCS.hlsl:444-514
+                Hit h = closestHitReferenceOrder(s, rd, r, bb, tri, cnt);
+                Surface sf = shadeFetch(s, r, h, cnt);
+                addLights(s, rd, r, sf, i, contribution, light, seed);
+                if (!sf.hit) alive = 0u;
+                else scatter(sf, r, contribution, light, seed);
+            }
+            o[0] = __uint_as_float(alive);
+            o[1] = r.origin.x; o[2] = r.origin.y; o[3] = r.origin.z;
+            o[4] = r.direction.x; o[5] = r.direction.y; o[6] = r.direction.z;
+            o[7] = __uint_as_float(seed);
+            break;
+        }
         default: break;
     }
 }

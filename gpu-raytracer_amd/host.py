@@ -178,7 +178,7 @@ class Context:
     def build_info(self):
         class _Info(C.Structure):
             _fields_ = [("builder", U32), ("num_nodes", U32), ("num_triangles", U32), ("max_depth", U32),
-                        ("device_ms", C.c_float), ("wall_ms", C.c_float)]
+                        ("device_ms", C.c_float), ("wall_ms", C.c_float), ("flags", U32)]
         bi = _Info()
         self._ck(self.fns.get_build_info(self.h, C.byref(bi)), "get_build_info")
         return {k: getattr(bi, k) for k, _ in _Info._fields_}

@@ -488,8 +488,13 @@ def sponza_proxy(tex_size=1024, env_face=1024, tri_scale=1.0):
     return s
 
 
-def small_mesh_scene(seed=3, n_objects=6, detail=10, with_textures=True, with_lights=False, transforms=False, tex_size=32, octree=(2, 2)):
-    """A tiny mixed scene for parity tests: blobs, a glass ball, a floor, spheres, optional lights."""
+def small_mesh_scene(seed=3, n_objects=6, detail=10, with_textures=True, with_lights=False, transforms=False, tex_size=32, octree=(2, 2),
+                     scales=None, bake_scale=False):
+    """A tiny mixed scene for parity tests: blobs, a glass ball, a floor, spheres, optional lights.
+
+    `scales` (with transforms=True): per-object Transform.scale, cycled over the blobs — a float for a uniform scale or a
+    3-tuple (Components.h:7-23; quirk Q3). `bake_scale=True` multiplies the same factors into the mesh vertices instead
+    and leaves the entity at unit scale: the same world-space geometry without the reference's local-vs-world cull."""
     rng = np.random.default_rng(seed)
     s = SceneDescription(f"small-{seed}")
     if with_textures:
@@ -504,7 +509,16 @@ def small_mesh_scene(seed=3, n_objects=6, detail=10, with_textures=True, with_li
             r = 1.5 + 1.0 * fbm3(dd * 2.0 + k, 50 + k, 2)
             base = np.zeros(3) if transforms else c
             return dd * r[..., None] + base
-        s.meshes.append(grid_surface(blob, 2 * detail, detail, (2, 1)))
+        sc3 = (1.0, 1.0, 1.0)
+        if transforms and scales:
+            v = scales[k % len(scales)]
+            sc3 = tuple(float(x) for x in v) if isinstance(v, (tuple, list)) else (float(v),) * 3
+        if bake_scale:
+            def blob_scaled(U, V, blob=blob, sc3=sc3):
+                return blob(U, V) * np.asarray(sc3)
+            s.meshes.append(grid_surface(blob_scaled, 2 * detail, detail, (2, 1)))
+        else:
+            s.meshes.append(grid_surface(blob, 2 * detail, detail, (2, 1)))
         mat = dict(albedo=tuple(rng.uniform(0.2, 1.0, 3)), roughness=float(rng.uniform(0, 1)), metallic=float(rng.uniform(0, 1)),
                    specular=float(rng.uniform(0, 1)))
         if with_textures and k % 2 == 0:
@@ -517,6 +531,8 @@ def small_mesh_scene(seed=3, n_objects=6, detail=10, with_textures=True, with_li
         if transforms:
             ent.position = tuple(c)
             ent.rotation = tuple(rng.uniform(-40, 40, 3))
+            if not bake_scale:
+                ent.scale = sc3
         s.entities.append(ent)
 
     def floor(U, V):

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OKRT_ABI_VERSION 1
+#define OKRT_ABI_VERSION 2
 
 typedef struct okrt_ctx okrt_ctx;
 
@@ -114,7 +114,14 @@ typedef enum okrt_option {
     /* 0 = reference-order traversal over the uploaded octree -> mesh -> BVH tables
      *     (RaytracerCS.hlsl:256-334, bit-identical visit order; produces the reference's
      *     bbCheckCount / triCheckCount);
-     * 1 = (default) the MI355X traversal structure derived from the same tables at commit. */
+     * 1 = (default) the MI355X traversal structure derived from the same tables at commit: instances are baked to
+     *     world space, so it returns the world-space closest hit. For rigid instances (every benchmark scene; identity
+     *     instances bit for bit) that IS the reference's result up to equal-distance ties. Under Transform.scale != 1
+     *     the reference culls per-mesh BVH boxes by a local-space distance against the world-space best hit (quirk Q3,
+     *     RaytracerCS.hlsl:273-287 vs :311-318): conservative — same picture — when every scale factor is >= 1, but
+     *     with a factor < 1 the reference skips boxes that hold the closest hit. Mode 1 does not reproduce those
+     *     drop-outs (tests/test_gpu_fullsize.py::test_scaled_instances_*); mode 0 does, exactly. okrt_get_build_info
+     *     reports OKRT_BUILD_FLAG_SHRUNK_INSTANCES so a host that needs the reference's artefacts can select mode 0. */
     OKRT_OPT_TRAVERSAL = 0,
     /* NUM_BOUNCES of RaytracerCS.hlsl:6 (default 1 = HEAD; a path has max_bounces+1 segments). */
     OKRT_OPT_MAX_BOUNCES = 1,
@@ -261,7 +268,14 @@ typedef struct okrt_build_info {
     uint32_t max_depth;      /* node levels + 1 */
     float device_ms;         /* device builder: first to last kernel on the stream; 0 for the host builder */
     float wall_ms;           /* host wall clock of the whole build incl. upload / read-backs */
+    uint32_t flags;          /* OKRT_BUILD_FLAG_*: what the instance table (t7) means for reference parity, see OKRT_OPT_TRAVERSAL */
 } okrt_build_info;
+/* some instance matrix is not a rigid motion (Transform.scale != 1, Components.h:7-23) */
+#define OKRT_BUILD_FLAG_SCALED_INSTANCES 1u
+/* some instance matrix shrinks at least one direction (a singular value < 1): there the reference's BVH cull compares a
+ * LARGER local-space box distance with the world-space best hit (quirk Q3, RaytracerCS.hlsl:285 vs :311-318) and drops
+ * geometry it should test; OKRT_TRAVERSAL_FAST returns the true closest hit instead (documented deviation) */
+#define OKRT_BUILD_FLAG_SHRUNK_INSTANCES 2u
 okrt_status okrt_get_build_info(okrt_ctx* ctx, okrt_build_info* out);
 /* Test / tooling access: copies the derived structure to the host (64 B per node, 48 B per triangle; layouts in
  * gpu-raytracer_amd/csrc/okrt_fast.h). Either pointer may be NULL. OKRT_ERR_STATE if nothing is built. */
@@ -287,12 +301,15 @@ okrt_status okrt_get_fast_structure(okrt_ctx* ctx, void* nodes64, uint32_t node_
  *   REFLECTANCE     cosine, index             -> value                   (RaytracerCS.hlsl:100-105)
  *   REFLECT_DIRECTION    d[3] n[3] roughness seed -> direction[3], new seed   (:107-112)
  *   TRANSPARENCY_BOUNCE  d[3] n[3] ior seed       -> direction[3], new seed   (:114-131)
- *   PRIMARY_RAY     px(bits) py(bits) RenderData[60 floats] -> origin[3], direction[3], seed   (:177-216, 430) */
+ *   PRIMARY_RAY     px(bits) py(bits) RenderData[60 floats] -> origin[3], direction[3], seed   (:177-216, 430)
+ *   SEGMENT_RAY     px(bits) py(bits) k(bits) RenderData[60 floats] -> alive?, origin[3], direction[3], seed
+ *                   (the ray entering path segment k of that pixel along the reference-order path, :444-514; k = 0 is
+ *                   the camera ray; alive = 0 when the path ended before segment k) */
 typedef enum okrt_kat {
     OKRT_KAT_PCG_HASH = 0, OKRT_KAT_RANDOM_FLOAT = 1, OKRT_KAT_RAY_SPHERE = 2, OKRT_KAT_RAY_TRIANGLE = 3, OKRT_KAT_RAY_AABB = 4,
     OKRT_KAT_REFRACT = 5, OKRT_KAT_SAMPLE_TEXTURE = 6, OKRT_KAT_SAMPLE_ENV = 7, OKRT_KAT_CLOSEST_HIT = 8,
     OKRT_KAT_CLOSEST_HIT_FAST = 9, OKRT_KAT_RANDOM_VECTOR = 10, OKRT_KAT_REFLECTANCE = 11, OKRT_KAT_REFLECT_DIRECTION = 12,
-    OKRT_KAT_TRANSPARENCY_BOUNCE = 13, OKRT_KAT_PRIMARY_RAY = 14
+    OKRT_KAT_TRANSPARENCY_BOUNCE = 13, OKRT_KAT_PRIMARY_RAY = 14, OKRT_KAT_SEGMENT_RAY = 15
 } okrt_kat;
 okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats);
 

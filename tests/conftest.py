@@ -21,6 +21,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def host_threads():
+    """Threads worth starting for the CPU checker: CPU count cut down to the affinity mask and the cgroup quota (a
+    one-GPU box shows 256 CPUs and grants its job a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError, IndexError):
+        pass
+    return n
+
+
 class Oracle:
     """The CPU oracle (oracle/liboracle.so): test infrastructure only."""
 
