@@ -27,6 +27,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:36)
+L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth of the 8 XCDs (same guide, "L2 (per XCD)")
 STRIPE_ROWS = 8
 GATHER_EVERY = 64
 
@@ -46,6 +47,40 @@ def algorithmic_bytes(c):
     traversal = 48 * c["n_oct"] + 232 * c["n_mesh"] + 36 * c["n_node"] + 36 * c["n_tri"]
     shading = 132 * c["mesh_hits"] + 16 * c["tex_taps"] + 16 * c["env_taps"] + 36 * c["pixels"]
     return traversal, shading
+
+
+def kernel_source_sha():
+    """Fingerprint of everything the device library is compiled from: a committed PMC measurement (profiles/*_pmc_*.json)
+    is only attached to a bench line produced by the same kernels."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(REPO, "gpu-raytracer_amd")
+    for f in sorted(glob.glob(os.path.join(pkg, "csrc", "*")) + [os.path.join(REPO, "include", "okrt.h"), os.path.join(pkg, "build.py")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(workload, frames_per_launch):
+    """Newest profiles/r*_pmc_<workload>_f<F>.json whose stamp matches these kernel sources and this launch-set size, else
+    (None, reason). The file is written by tools/pmc_traffic.py from rocprofv3 --pmc passes of this same bench command."""
+    import glob
+    best, why = None, "no profiles/r*_pmc_%s_f*.json" % workload
+    sha = kernel_source_sha()
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_%s_f*.json" % workload))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("source_sha") != sha:
+            why = f"{os.path.basename(f)} was measured on other kernel sources ({j.get('source_sha')} != {sha})"
+            continue
+        if j.get("frames_per_launch") != frames_per_launch:
+            why = f"{os.path.basename(f)} was measured with launch sets of {j.get('frames_per_launch')} frames, this run uses {frames_per_launch}"
+            continue
+        best = (os.path.basename(f), j)
+    return (best, None) if best else (None, why)
 
 
 def usable_cpus():
@@ -124,6 +159,104 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
                       f"1 thread: {rows1} rows, {rays1} rays in {dt1:.1f} s"}
 
 
+def roofline_report(args, world, samples_split, interval_ms, launches, frames, build, ref_c, fast_c, cam_c, ref_trav_bytes,
+                    ref_shade_bytes, trace_ms_frame, shade_ms_frame, other_ms_frame):
+    """The roofline object of the JSON line (DESIGN.md §4 "Roofline accounting").
+
+    Per kernel of the fast pipeline, live: average launch duration from the HIP events the library records around every
+    kernel on the stream it runs on (okrt_get_interval_ms), and the kernel's ALGORITHMIC bytes per launch = what its own
+    algorithm has to move through HBM at least once (ray / hit / queue / framebuffer records at their real sizes, one
+    shading record per hit, 16 B per texture tap, the traversal structure once per launch) — a lower bound of its HBM
+    traffic, so algorithmic_frac <= 1. `traffic` is the MEASURED HBM-side bytes per launch of the same kernel (rocprofv3
+    --pmc FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.py -> profiles/r*_pmc_<workload>.json) and only attached when that
+    file was measured on these kernel sources and this launch-set size; `frac` = traffic / time / peak when it is,
+    else the algorithmic fraction with traffic = null and traffic_stale = true. The headline kernel is the one with the
+    largest share of the frame."""
+    per_gpu = world if not samples_split else 1  # counters are whole-frame sums; a rank traces 1 / world of the pixels
+    launches = max(launches, 1)
+    frames_per_launch = max(frames // launches, 1)
+    structure_bytes = 64 * build["num_nodes"] + 48 * build["num_triangles"]
+    pixels, segs = fast_c["pixels"], fast_c["segments"]
+    bounce_rays = max(segs - pixels, 0)          # rays of segments 1..: queue entries the camera kernel / shading kernels append
+    cam_nodes, cam_tris = cam_c["fast_nodes"], cam_c["fast_tris"]            # lane-level counts (x64 per wave-uniform visit)
+    b_nodes, b_tris = fast_c["fast_nodes"] - cam_nodes, fast_c["fast_tris"] - cam_tris
+    cam_hits, cam_taps, cam_env = cam_c["mesh_hits"], cam_c["tex_taps"], cam_c["env_taps"]
+    later_hits, later_taps, later_env = fast_c["mesh_hits"] - cam_hits, fast_c["tex_taps"] - cam_taps, fast_c["env_taps"] - cam_env
+    slot = 16 if frames_per_launch > 1 else 36   # a finished path: 16-byte radiance slot (F > 1) or accumulation RMW + resolve
+    mb = args.max_bounces
+    kernels = []
+
+    def add(name, ms_sum, alg_frame, l2_frame, once=0):
+        if ms_sum <= 0:
+            return
+        launch_ms = ms_sum / launches
+        alg = alg_frame / per_gpu * frames_per_launch + once
+        l2 = l2_frame / per_gpu * frames_per_launch
+        kernels.append({"kernel": name, "launch_ms": round(launch_ms, 4), "ms_per_frame": round(launch_ms / frames_per_launch, 5),
+                        "algorithmic_bytes_per_launch": int(alg), "algorithmic_gbs": round(alg / (launch_ms * 1e-3) / 1e9, 1),
+                        "algorithmic_frac": round(alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "l2_request_bytes_per_launch": int(l2), "l2_frac": round(l2 / (launch_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)})
+
+    if args.traversal == "fast" and len(interval_ms) >= 2:
+        # camera-segment kernel: generates, traces (wave-uniform node / triangle loads: once per WAVE), shades, appends queue 1
+        cam_surv = bounce_rays if mb == 1 else (cam_hits if mb > 1 else 0)  # (mb > 1: every camera hit continues)
+        cam_alg = 56 * cam_surv + slot * max(pixels - cam_surv, 0) + 64 * cam_hits + 16 * cam_taps + 16 * cam_env
+        cam_l2 = (64 * cam_nodes + 48 * cam_tris) / 64 + cam_alg
+        add("tracePacketKernel<FUSED> (camera segment: generate + packet traversal + shade + append)", interval_ms[0] + interval_ms[1], cam_alg, cam_l2,
+            structure_bytes)
+        if mb >= 1 and len(interval_ms) >= 4:
+            tr = sum(interval_ms[2::2])
+            sh = sum(interval_ms[3::2])
+            # traceKernel: 32 B ray read + 20 B hit record write per ray; per-lane gathers of 64 B per node visit, 48 B per triangle test
+            add("traceKernel (bounce-ray traversal)", tr, 52 * bounce_rays, 64 * b_nodes + 48 * b_tris + 52 * bounce_rays, structure_bytes * mb)
+            later_surv = max(bounce_rays - cam_surv, 0)  # rays of segments 2..: appended by the later shading kernels
+            sh_alg = (56 + 20) * bounce_rays + 64 * later_hits + 16 * later_taps + 16 * later_env + slot * max(bounce_rays - later_surv, 0) + 56 * later_surv
+            if frames_per_launch > 1:
+                sh_alg += (16 * frames_per_launch + 36) * pixels / frames_per_launch  # accumulateKernel: all slots once + accum RMW + resolve
+            add("shadeKernel<NEXT> + accumulateKernel (later segments: fetch, lights, BSDF, frame-slot accumulation)", sh, sh_alg, sh_alg)
+    elif interval_ms:
+        add("renderReferenceOrder (reference-order megakernel)", interval_ms[0], ref_trav_bytes + ref_shade_bytes, ref_trav_bytes + ref_shade_bytes)
+    if not kernels:
+        return {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+    head = max(kernels, key=lambda k: k["launch_ms"])
+    pmc, why = load_pmc(args.workload, frames_per_launch) if world == 1 and args.max_bounces == 1 else (None, "PMC files are measured at N = 1, NUM_BOUNCES = 1")
+    traffic = lane_util = l2_hit = None
+    if pmc:
+        fname, j = pmc
+        for k in kernels:
+            short = k["kernel"].split(" ")[0].split("<")[0]
+            m = j.get("kernels", {}).get(short)
+            if m:
+                k["traffic"] = int(m["hbm_bytes_per_launch"])
+                k["traffic_frac"] = round(m["hbm_bytes_per_launch"] / (k["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                k["l2_hit_pct"] = m.get("l2_hit_pct")
+                k["valu_lane_util"] = m.get("valu_lane_util")
+        traffic, lane_util, l2_hit = head.get("traffic"), head.get("valu_lane_util"), head.get("l2_hit_pct")
+    measured = traffic is not None
+    achieved = (traffic if measured else head["algorithmic_bytes_per_launch"]) / (head["launch_ms"] * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "kernel": head["kernel"], "launch_ms": head["launch_ms"], "frames_per_launch": frames_per_launch,
+        "launches_timed": launches,
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "frac_basis": "measured HBM-side bytes (traffic) / live launch time / peak" if measured else "algorithmic bytes (lower bound of HBM traffic) / live launch time / peak",
+        "traffic": traffic, "traffic_stale": not measured,
+        "traffic_source": pmc[0] if pmc else why,
+        "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "algorithmic_frac": head["algorithmic_frac"],
+        "l2_frac": head["l2_frac"], "l2_hit_pct": l2_hit, "valu_lane_util": lane_util,
+        "kernels": kernels,
+        "node4q_visits_per_bounce_ray": round(b_nodes / max(bounce_rays, 1), 2), "tri48_tests_per_bounce_ray": round(b_tris / max(bounce_rays, 1), 2),
+        "node4q_steps_per_camera_tile": round(cam_nodes / 64 / max(pixels / 64, 1), 2), "tri48_tests_per_camera_tile": round(cam_tris / 64 / max(pixels / 64, 1), 2),
+        "structure_bytes": structure_bytes,
+        "traversal_ms_per_frame": round(trace_ms_frame, 4), "later_shading_ms_per_frame": round(shade_ms_frame, 4), "other_ms_per_frame": round(other_ms_frame, 4),
+        # SURVEY.md §8d to the letter, kept under its own name: the bytes the REFERENCE's octree -> mesh -> BVH order would touch
+        # for these rays over the traversal time. Far above 1: it measures the work the derived structure avoids, not a bandwidth.
+        "reference_work_ratio": round(ref_trav_bytes / per_gpu / max(trace_ms_frame * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 2),
+        "reference_algorithmic_bytes_per_ray": round(ref_trav_bytes / max(ref_c["segments"], 1), 1),
+        "note": "frac <= 1 by construction. The traversal kernels are latency-bound (dependent gathers served by L2 / Infinity Cache: the structure is "
+                "cache-resident), so their HBM fraction is low; the later-segment shading kernels are the HBM-bound part (kernels[].algorithmic_frac).",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-call", action="store_true", help="skip the one-okrt_render-per-frame timing (profiling runs: every launch set then has frames_per_launch frames)")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
+    ap.add_argument("--max-bounces", type=int, default=1, help="NUM_BOUNCES (RaytracerCS.hlsl:6; HEAD = 1, used for every graded number)")
     ap.add_argument("--split", default="tiles", choices=["tiles", "samples"],
                     help="N > 1: 'tiles' = image-space stripes + gather (the north-star path); 'samples' = every rank renders "
                          "the whole frame for its own block of frame indices, accumulations are summed with one reduce")
@@ -181,6 +315,7 @@ def main():
     rt, scene, res = scenes.instantiate(desc, W, H, device=device_index)
     ctx = rt.ctx
     ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
+    ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
 
     if world == 1 and os.environ.get("OKRT_BENCH_TILE"):  # developer knob: time one rank's share of an N-way split on 1 GPU
         sr, si, ss = (int(v) for v in os.environ["OKRT_BENCH_TILE"].split(","))
@@ -243,6 +378,13 @@ def main():
         ctx.reset_counters()
         rt.render()  # same frame index through the fast pipeline: its own node / triangle visit counts
         fast_counters = ctx.counters()
+        # the camera segment alone (max_bounces = 0): splits the node / triangle visit counts between the two traversal kernels
+        ctx.set_option(abi.OPT_MAX_BOUNCES, 0)
+        rt.resetAccumulation()
+        ctx.reset_counters()
+        rt.render()
+        camera_counters = ctx.counters()
+        ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
         ctx.set_option(abi.OPT_COUNTERS, 0)
         ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
         rt.resetAccumulation()
@@ -286,6 +428,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
+    interval_ms, interval_launches, interval_frames = ctx.interval_ms()  # per kernel, launch sets of the size of the last one
+    build = ctx.build_info()
     ctx.set_option(abi.OPT_TIMING, 0)
     rays_local = ctx.counters()["segments"]
     if args.traversal == "reference":  # the reference-order kernel only counts with OKRT_OPT_COUNTERS (slow): segments of the counted frame x frames
@@ -319,6 +463,9 @@ def main():
         fast_t = torch.tensor([float(fast_counters[k]) for k in sorted(fast_counters)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(fast_t, op=dist.ReduceOp.SUM)
         fast_counters = {k: int(v) for k, v in zip(sorted(fast_counters), fast_t.tolist())}
+        cam_t = torch.tensor([float(camera_counters[k]) for k in sorted(camera_counters)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(cam_t, op=dist.ReduceOp.SUM)
+        camera_counters = {k: int(v) for k, v in zip(sorted(camera_counters), cam_t.tolist())}
         st = torch.tensor([trace_ms, shade_ms, other_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
         trace_ms, shade_ms, other_ms = st.tolist()
@@ -335,50 +482,23 @@ def main():
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
         mrays = rays_total / elapsed_max / 1e6
-        trav_bytes, shade_bytes = algorithmic_bytes(ref_counters)
+        ref_trav_bytes, ref_shade_bytes = algorithmic_bytes(ref_counters)
         frames = max(timed_frames, 1)
         trace_ms_frame = trace_ms / frames
-        achieved = trav_bytes / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0  # GB/s, whole frame's traversal
-        # what the kernel's OWN algorithm has to move per frame: 64 B per Node4Q visit, 48 B per Tri48 test, 32 B ray read
-        # + 20 B hit record per ray, 32 B camera-ray write per pixel (okrt_fast.h)
-        own_bytes = (64 * fast_counters["fast_nodes"] + 48 * fast_counters["fast_tris"] + 52 * fast_counters["segments"]
-                     + 32 * fast_counters["pixels"])
-        # per GPU: every rank traces 1/world of the frame; the stage time is the slowest rank's
-        per_gpu = 1 if samples_split else world  # the counters come from each rank's own pixels
-        trav_bytes_gpu, own_bytes_gpu = trav_bytes / per_gpu / (world if samples_split else 1), own_bytes / per_gpu / (world if samples_split else 1)
-        achieved = trav_bytes_gpu / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
-        own_achieved = own_bytes_gpu / (trace_ms_frame * 1e-3) / 1e9 if trace_ms_frame > 0 else 0.0
+        fpl_used = max(1, min(fpl, steps_here))  # the launch-set size the timed region really used
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "traversal": args.traversal, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl, "gpu_event_ms_per_step": round(ctx.timer_elapsed_ms() / max(steps_here, 1), 4), "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None, "ms_per_step_one_call_per_frame_defer_off": round(single_sync_ms, 4) if single_sync_ms else None,
+            "config": {"workload": wl_desc, "traversal": args.traversal, "max_bounces": args.max_bounces, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl_used, "gpu_event_ms_per_step": round(ctx.timer_elapsed_ms() / max(steps_here, 1), 4), "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None, "ms_per_step_one_call_per_frame_defer_off": round(single_sync_ms, 4) if single_sync_ms else None,
                        "tile_split": ("samples split: every rank renders the whole frame for its own block of frame indices" if samples_split else
                                       f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks") if world > 1 else "full frame",
                        "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "
                                   f"every {GATHER_EVERY} frames + final") if world > 1 else "none"},
-            "roofline": {
-                "bound": "hbm", "kernel": "camera-segment kernel (ray generation + packet traversal + first shading, fused) + traceKernel (bounce rays), per GPU; the traversal time therefore includes the camera segment's shading",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "algorithmic_bytes_per_frame": trav_bytes, "algorithmic_bytes_per_ray": round(trav_bytes / max(ref_counters["segments"], 1), 1),
-                "kernel_ms_per_frame": round(trace_ms_frame, 4), "shade_ms_per_frame": round(shade_ms / frames, 4),
-                "other_ms_per_frame": round(other_ms / frames, 4),
-                "kernel_own_bytes_per_frame": own_bytes, "kernel_own_achieved": round(own_achieved, 1),
-                "kernel_own_frac": round(own_achieved / HBM_PEAK_GBS, 4),
-                "node4q_visits_per_ray": round(fast_counters["fast_nodes"] / max(fast_counters["segments"], 1), 2),
-                "tri48_tests_per_ray": round(fast_counters["fast_tris"] / max(fast_counters["segments"], 1), 2),
-                "frame_frac": round((trav_bytes + shade_bytes) / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "algorithmic bytes = what the REFERENCE's octree->mesh->BVH traversal order touches for the same rays "
-                        "(SURVEY.md 8d); the derived BVH4 visits far fewer, so frac may exceed 1. kernel_own_* prices the "
-                        "bytes the fast kernel's own node/triangle visits move (mostly L2/Infinity-Cache hits, see traffic)"},
         }
-        pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and args.workload == "sponza" and world == 1:
-            try:
-                out["roofline"]["traffic"] = json.load(open(pmc)).get("trace_hbm_bytes_per_frame")
-            except Exception:
-                pass
+        out["roofline"] = roofline_report(args, world, samples_split, interval_ms, interval_launches, interval_frames, build,
+                                          ref_counters, fast_counters, camera_counters, ref_trav_bytes, ref_shade_bytes, trace_ms_frame,
+                                          shade_ms / frames, other_ms / frames)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, W, H, None)
         print(json.dumps(out), flush=True)

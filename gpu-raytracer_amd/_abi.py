@@ -88,6 +88,7 @@ PRODUCT_ONLY = {
     "timer_elapsed_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "last_render_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
     "get_stage_ms": (C.c_int, [P, C.POINTER(C.c_float * 3), C.POINTER(U32)]),
+    "get_interval_ms": (C.c_int, [P, C.POINTER(C.c_float), U32, C.POINTER(U32), C.POINTER(U32), C.POINTER(U32)]),
     "write_accum_f32x4": (C.c_int, [P, P]),
     "get_api": (P, []),
     "commit": (C.c_int, [P]),

@@ -155,6 +155,7 @@ okrt_status allocFramebuffers(okrt_ctx* c) {
     if ((s = ensure(c, c->resultOwn, px * 4)) != OKRT_OK) return s;
     c->accum = (float4*)c->accumOwn.ptr;
     c->result = (uint32_t*)c->resultOwn.ptr;
+    c->externalFramebuffers = false;  // okrt_resize / okrt_set_tile rebind to the library's own buffers (okrt.h: re-bind after them)
     if (px) {
         OKRT_HIP(c, hipMemsetAsync(c->accum, 0, px * sizeof(float4), c->stream));
         OKRT_HIP(c, hipMemsetAsync(c->result, 0, px * 4, c->stream));
@@ -606,44 +607,49 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
 
     SceneView view = makeView(c);
     unsigned long long* counters = c->countersOn ? (unsigned long long*)c->counters.ptr : nullptr;
+    const bool referenceOrder = c->traversal == OKRT_TRAVERSAL_REFERENCE || rd->debugMode != 0;
+    if (!referenceOrder) {
+        okrt_status fs = ensureFast(c);
+        if (fs != OKRT_OK) return fs;
+    }
+    // OKRT_OPT_TIMING: the launch set records into the ring's next slot; the slot is only claimed (ringNext / ringCount
+    // advance) once the launches succeeded, so a refused or failed attempt leaves the ring as it was
     okrt_ctx::TimedFrame* tf = nullptr;
     if (c->timingOn && !c->ring.empty()) {
         tf = &c->ring[c->ringNext];
-        c->ringNext = (c->ringNext + 1) % c->ring.size();
-        c->ringCount = std::min(c->ringCount + 1, c->ring.size());
         const size_t need = 2 * (size_t)(c->maxBounces + 1) + 1;
         while (tf->ev.size() < need) {
             hipEvent_t e;
             OKRT_HIP(c, hipEventCreate(&e));
             tf->ev.push_back(e);
         }
-        tf->used = 0;
-        tf->frames = frames;
     }
+    int used = 0;
     // The debug heat maps count the REFERENCE traversal's box/triangle checks (RaytracerCS.hlsl:516-520),
     // so those frames always run the reference-order kernel.
-    if (c->traversal == OKRT_TRAVERSAL_REFERENCE || rd->debugMode != 0) {
+    if (referenceOrder) {
         if (tf) OKRT_HIP(c, hipEventRecord(tf->ev[0], c->stream));
         launchReferenceOrder(view, *rd, c->tile, c->accum, c->result, counters, c->stream);
-        if (tf) {
-            OKRT_HIP(c, hipEventRecord(tf->ev[1], c->stream));
-            tf->used = 2;
-            tf->fast = false;
-        }
+        if (tf) OKRT_HIP(c, hipEventRecord(tf->ev[1], c->stream));
+        used = 2;
     } else {
-        okrt_status fs = ensureFast(c);
-        if (fs != OKRT_OK) return fs;
         std::string msg;
-        if (!launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, (unsigned long long*)c->counters.ptr, c->stream,
-                        tf ? tf->ev.data() : nullptr, frames, msg))
-            return fail(c, OKRT_ERR_OOM, "fast pipeline: " + msg);
-        if (tf) {
-            tf->used = 2 * (c->maxBounces + 1) + 1;
-            tf->fast = true;
-        }
+        const LaunchStatus ls = launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, (unsigned long long*)c->counters.ptr, c->stream,
+                                           tf ? tf->ev.data() : nullptr, frames, msg);
+        if (ls != LaunchStatus::Ok)
+            return fail(c, ls == LaunchStatus::OutOfMemory ? OKRT_ERR_OOM : ls == LaunchStatus::Invalid ? OKRT_ERR_INVALID_ARG : OKRT_ERR_DEVICE,
+                        "fast pipeline: " + msg);
+        used = 2 * (c->maxBounces + 1) + 1;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (tf) {
+        tf->used = used;
+        tf->fast = !referenceOrder;
+        tf->frames = frames;
+        c->ringNext = (c->ringNext + 1) % c->ring.size();
+        c->ringCount = std::min(c->ringCount + 1, c->ring.size());
+    }
     return OKRT_OK;
 }
 
@@ -817,6 +823,32 @@ okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames
         if (s != OKRT_OK) return s;
         for (int k = 0; k < 3; ++k) out_ms[k] += st[k];
         *out_frames += c->ring[i].frames;
+    }
+    return OKRT_OK;
+}
+
+okrt_status okrt_get_interval_ms(okrt_ctx* c, float* out_ms, uint32_t capacity, uint32_t* out_count, uint32_t* out_launches, uint32_t* out_frames) {
+    if (!c || !out_ms || !out_count || !out_launches || !out_frames) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
+    OKRT_HIP(c, hipSetDevice(c->device));
+    *out_count = *out_launches = *out_frames = 0;
+    if (!c->ringCount) return OKRT_OK;
+    const okrt_ctx::TimedFrame& newest = c->ring[(c->ringNext + c->ring.size() - 1) % c->ring.size()];
+    if (newest.used < 2) return OKRT_OK;
+    const int n = newest.used - 1;
+    *out_count = (uint32_t)n;
+    for (uint32_t k = 0; k < capacity && k < (uint32_t)n; ++k) out_ms[k] = 0.f;
+    for (size_t i = 0; i < c->ringCount; ++i) {
+        const okrt_ctx::TimedFrame& f = c->ring[i];
+        if (f.used != newest.used || f.fast != newest.fast) continue;
+        OKRT_HIP(c, hipEventSynchronize(f.ev[f.used - 1]));
+        for (int k = 0; k < n; ++k) {
+            float ms = 0.f;
+            OKRT_HIP(c, hipEventElapsedTime(&ms, f.ev[k], f.ev[k + 1]));
+            if ((uint32_t)k < capacity) out_ms[k] += ms;
+        }
+        *out_launches += 1;
+        *out_frames += f.frames;
     }
     return OKRT_OK;
 }

@@ -123,15 +123,16 @@ void fastSetQueueBudget(FastScene** scene, size_t bytes);
 // copies the structure back to the host (tests); either pointer may be null
 bool fastReadStructure(const FastScene* scene, void* nodes, uint32_t nodeCapacity, void* tris, uint32_t triCapacity, hipStream_t stream, std::string& err);
 void fastDestroy(FastScene* scene);
-// One frame through the wavefront pipeline. Returns false (with err) if queue memory cannot be had.
+// One launch set through the wavefront pipeline. OutOfMemory (with err) if queue memory cannot be had.
 // `counters` (optional) = full okrt_counters accounting; `rayTotals` (always) = the same buffer, of which
 // only pixels/segments are bumped, by one atomic per trace launch. `events` (optional): 2*(max_bounces+1)+1 events recorded before/after every kernel, in launch order.
 // `frames` >= 1 consecutive frames (numAccumulationFrames = rd's value, +1, +2, ...) are traced by ONE set of launches;
 // their radiance lands in per-frame slots and is added to `accum` in frame order, so the result is bit-identical to
 // `frames` single-frame calls (frames > 1 requires accumulationEnabled == 1).
-bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum,
-                uint32_t* result, unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events,
-                uint32_t frames, std::string& err);
+enum class LaunchStatus { Ok, OutOfMemory /* queues do not fit (budget or allocator): retry with fewer frames */, Invalid, Device };
+LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum,
+                        uint32_t* result, unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events,
+                        uint32_t frames, std::string& err);
 constexpr uint32_t kMaxFramesPerLaunch = 64;
 
 }  // namespace okrt

@@ -140,6 +140,7 @@ void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const u
 void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
                  RayQueue qIn, HitBuffer hb, const ShardView& in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce, uint32_t lastBounce,
                  float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters);
+void launchSetRenderData(hipStream_t stream, const okrt_render_data& rd, okrt_render_data* dst);
 void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t pixels, uint32_t frames, const float4* radiance, float4* accum,
                       uint32_t* result);
 void launchFastKat(hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats,

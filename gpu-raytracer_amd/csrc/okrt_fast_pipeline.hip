@@ -191,14 +191,20 @@ void fastDestroy(FastScene* fs) {
     delete fs;
 }
 
-bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
-                unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
-                std::string& err) {
+LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
+                        unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
+                        std::string& err) {
     const uint32_t perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
     if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)perFrame * frames > 0x7FFFFFFFull) {
         err = "frames per launch out of range";
-        return false;
+        return LaunchStatus::Invalid;
     }
+    hipError_t he = hipSuccess;
+    auto hipFailed = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return false;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return true;
+    };
     const uint32_t total = perFrame * frames;
     const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
     const size_t items = (size_t)cap * kShards;
@@ -206,14 +212,14 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     const size_t needBytes = items * (2 * 56 + 20) + (frames > 1 ? (size_t)t.rows * t.W * frames * 16 : 0);
     if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
         err = "launch set exceeds the queue memory budget";
-        return false;
+        return LaunchStatus::OutOfMemory;
     }
     if (items > fs.capacity) {
         hipStreamSynchronize(stream);
         fs.capacity = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
         for (RayQueue& q : fs.q)
-            if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return false;
-        if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return false;
+            if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return LaunchStatus::OutOfMemory;
+        if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return LaunchStatus::OutOfMemory;
         fs.capacity = items;
     }
     const size_t pixels = (size_t)t.rows * t.W;
@@ -222,7 +228,7 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
         if (pixels * frames > fs.radianceCap) {
             hipStreamSynchronize(stream);
             fs.radianceCap = 0;
-            if (!devAlloc(&fs.radiance, pixels * frames, err)) return false;
+            if (!devAlloc(&fs.radiance, pixels * frames, err)) return LaunchStatus::OutOfMemory;
             fs.radianceCap = pixels * frames;
         }
         radiance = fs.radiance;
@@ -230,15 +236,19 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     const uint32_t lastBounce = s.maxBounces;
     if (lastBounce + 2 > kMaxSegments) {
         err = "max_bounces too large for the fast pipeline";
-        return false;
+        return LaunchStatus::Invalid;
     }
-    hipMemsetAsync(fs.counts, 0, (size_t)kCountWords * sizeof(uint32_t), stream);
+    if (!fs.rdDev && !devAlloc(&fs.rdDev, 1, err)) return LaunchStatus::OutOfMemory;
+    if (hipFailed(hipMemsetAsync(fs.counts, 0, (size_t)kCountWords * sizeof(uint32_t), stream), "hipMemsetAsync(queue counters)")) return LaunchStatus::Device;
     FastView fv{fs.nodes.p, fs.tris.p, fs.overflow, fs.overflowCap};
     const dim3 tg(fs.traceBlocks);
     const dim3 sg((unsigned)(items / 256));
     const bool cnt = counters != nullptr;
     int ev = 0;
-    auto mark = [&]() { if (events) hipEventRecord(events[ev++], stream); };
+    auto mark = [&]() {
+        if (events && he == hipSuccess) he = hipEventRecord(events[ev], stream);
+        ev++;
+    };
     static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
     static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
     static const uint32_t envNodeMin = getenv("OKRT_FAST_NODE_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_NODE_MIN")) : 32u;
@@ -254,8 +264,9 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
     const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
     const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
-    if (!fs.rdDev && !devAlloc(&fs.rdDev, 1, err)) return false;
-    hipMemcpyAsync(fs.rdDev, &rd, sizeof(rd), hipMemcpyHostToDevice, stream);  // stream order: the previous launch set has read its copy
+    // the launch set's RenderData in device memory, written by a kernel from its by-value argument: stream-ordered after
+    // the previous launch set's readers, and no pageable-memory staging on the host side of an asynchronous call
+    launchSetRenderData(stream, rd, fs.rdDev);
     const FusedArgs fa{perFrame, fs.q[1], fs.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, fs.rdDev};
     const uint32_t pixels32 = (uint32_t)pixels;
     if (packet && envFused) {
@@ -284,7 +295,8 @@ bool launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, c
         if (b == lastBounce && radiance) launchAccumulate(stream, rd, pixels32, frames, radiance, accum, result);
         mark();
     }
-    return true;
+    if (hipFailed(he, "hipEventRecord") || hipFailed(hipGetLastError(), "kernel launch")) return LaunchStatus::Device;
+    return LaunchStatus::Ok;
 }
 
 }  // namespace okrt

@@ -119,7 +119,17 @@ __global__ __launch_bounds__(256) void accumulateKernel(okrt_render_data rd, uin
     result[p] = toUnorm8(a.x / n) | (toUnorm8(a.y / n) << 8) | (toUnorm8(a.z / n) << 16) | (toUnorm8(a.w / n) << 24);
 }
 
+// RenderData from the kernel-argument segment into device memory (what the fused camera kernel reads).
+__global__ __launch_bounds__(64) void setRenderDataKernel(okrt_render_data rd, okrt_render_data* dst) {
+    static_assert(sizeof(okrt_render_data) == 60 * sizeof(uint32_t), "RenderData is 60 words");
+    if (threadIdx.x < 60) reinterpret_cast<uint32_t*>(dst)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&rd)[threadIdx.x];
+}
+
 }  // namespace
+
+void launchSetRenderData(hipStream_t stream, const okrt_render_data& rd, okrt_render_data* dst) {
+    hipLaunchKernelGGL(setRenderDataKernel, dim3(1), dim3(64), 0, stream, rd, dst);
+}
 
 void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames) {
     hipLaunchKernelGGL(generateKernel, grid, dim3(256), 0, stream, rd, tile, q, perFrame, frames);

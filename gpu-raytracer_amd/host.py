@@ -158,6 +158,13 @@ class Context:
         self._ck(self.fns.get_stage_ms(self.h, C.byref(ms), C.byref(n)), "get_stage_ms")
         return ms[0], ms[1], ms[2], n.value
 
+    def interval_ms(self):
+        """([ms per kernel interval, summed over the ring's launch sets], launch sets, frames): okrt_get_interval_ms."""
+        ms = (C.c_float * 160)()
+        n, launches, frames = U32(), U32(), U32()
+        self._ck(self.fns.get_interval_ms(self.h, ms, 160, C.byref(n), C.byref(launches), C.byref(frames)), "get_interval_ms")
+        return [ms[k] for k in range(min(n.value, 160))], launches.value, frames.value
+
     def bind_framebuffers(self, accum_ptr, result_ptr):
         self._ck(self.fns.bind_framebuffers(self.h, accum_ptr, result_ptr), "bind_framebuffers")
 

@@ -139,7 +139,7 @@ bool loadObjects(const std::string& filePath, std::vector<ObjObject>& outObjects
             while (in >> tok) poly.push_back(parseIdx(tok, (int)V.size(), (int)T.size() / 2, (int)N.size()));
             if (poly.size() < 3) continue;
             for (const Idx& i : poly)
-                if (i.v < 1 || i.v > (int)V.size() || i.t > (int)T.size() / 2 || i.n > (int)N.size()) {
+                if (i.v < 1 || i.v > (int)V.size() || i.t < 0 || i.t > (int)T.size() / 2 || i.n < 0 || i.n > (int)N.size()) {  // 0 = absent; relative indices are resolved by parseIdx
                     error = "index out of range at line " + std::to_string(lineNo);
                     return false;
                 }

@@ -256,6 +256,14 @@ okrt_status okrt_last_render_ms(okrt_ctx* ctx, float* out_ms);
  * out_ms[1] = the shading kernels of the later segments, out_ms[2] = everything else inside the frame (memsets,
  * gaps). *out_frames = number of frames summed. Synchronises. */
 okrt_status okrt_get_stage_ms(okrt_ctx* ctx, float out_ms[3], uint32_t* out_frames);
+/* The same ring, kernel by kernel: out_ms[k] = device time between event k and k + 1 of a launch set, summed over the
+ * launch sets in the ring (those with the same number of intervals as the newest one). For the fast pipeline the
+ * intervals are, in launch order: 0 = the camera-segment kernel, 1 = (frame-slot accumulation when max_bounces == 0),
+ * then per later segment b = 1.. : 2b = traceKernel, 2b + 1 = shadeKernel (+ the frame-slot accumulation after the last);
+ * the reference-order traversal has one interval. *out_count = number of intervals (at most `capacity` are written),
+ * *out_launches = launch sets summed, *out_frames = frames they traced. Synchronises. */
+okrt_status okrt_get_interval_ms(okrt_ctx* ctx, float* out_ms, uint32_t capacity, uint32_t* out_count, uint32_t* out_launches,
+                                 uint32_t* out_frames);
 
 /* Validates the uploaded tables and (re)builds the derived traversal structure now instead of inside the next
  * okrt_render — the reference's "Rebuild BVH / refresh octree" moment (Application.cpp:312-317,598-604). Optional:

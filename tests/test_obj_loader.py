@@ -109,3 +109,8 @@ def test_errors(tmp_path):
     (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
     with pytest.raises(abi.OkrtError, match="out of range"):
         res.import_obj(str(tmp_path / "bad.obj"))
+    # relative texture / normal indices that point before the first element stay negative after resolution
+    for face in ("f 1/-100 2/1 3/1", "f 1/1/-7 2/1/1 3/1/1"):
+        (tmp_path / "neg.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n" + face + "\n")
+        with pytest.raises(abi.OkrtError, match="out of range"):
+            res.import_obj(str(tmp_path / "neg.obj"))

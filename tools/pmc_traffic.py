@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Measured per-kernel numbers for bench.py's roofline object, from rocprofv3 passes of the SAME bench command.
+
+  python3 tools/pmc_traffic.py --workload sponza --frames 64 --out gpurun_out/pmc    (on the GPU box, via gpurun)
+
+Four separate passes (counters never share a run with --stats; FETCH_SIZE and WRITE_SIZE do not fit one pass:
+MI355X_MICROARCH.md "rocprofv3 PMC slots"):
+  1. --kernel-trace --stats                     per-kernel launch durations (must agree with bench.py's HIP-event times)
+  2. --pmc FETCH_SIZE                           L2 -> fabric read bytes (KiB; x2 on gfx950 for 16-B-per-lane reads: upper bound)
+  3. --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum  fabric write bytes (KiB, exact), L2 hit rate
+  4. --pmc SQ_* (8 slots)                       VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), wait shares
+Every bench run uses --steps F --warmup F --frames-per-launch F, so every launch of the non-counting kernel variants
+traces exactly F frames and "per launch" is well defined.
+
+Writes <out>/pmc_<workload>_f<F>.json (+ .txt), stamped with the kernel-source fingerprint bench.py checks before it
+attaches `traffic` to a bench line; tools/stamp_profile.py copies it under profiles/ with the git head.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+PASSES = [
+    ("stats", ["--kernel-trace", "--stats"]),
+    ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
+    ("write", ["--pmc", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "--kernel-trace"]),
+    ("sq", ["--pmc", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
+            "SQ_WAIT_INST_ANY", "--kernel-trace"]),
+]
+FAMILIES = ("tracePacketKernel", "traceKernel", "shadeKernel", "accumulateKernel", "generateKernel", "renderReferenceOrder")
+
+
+def family(name):
+    """(family, counting variant?) of a kernel name; None for kernels that are not part of the frame."""
+    m = re.search(r"(tracePacketKernel|traceKernel|shadeKernel|accumulateKernel|generateKernel|renderReferenceOrder)(<([^>]*)>)?", name)
+    if not m:
+        return None, False
+    args = [a.strip() for a in (m.group(3) or "").split(",")] if m.group(3) else []
+    fam = m.group(1)
+    counting = (fam in ("tracePacketKernel", "traceKernel") and args[:1] == ["true"]) or (fam == "shadeKernel" and args[1:2] == ["true"])
+    return fam, counting
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="sponza")
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--out", default="gpurun_out/pmc")
+    ap.add_argument("--passes", default="stats,fetch,write,sq")
+    args = ap.parse_args()
+    import bench
+    os.makedirs(args.out, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    tag = f"{args.workload}_f{args.frames}"
+    cmd = ["python3", os.path.join(REPO, "bench.py"), "--workload", args.workload, "--steps", str(args.frames), "--warmup", str(args.frames),
+           "--frames-per-launch", str(args.frames), "--no-cpu-baseline", "--no-single-call"]
+    bench_lines = {}
+    for name, flags in PASSES:
+        if name not in args.passes.split(","):
+            continue
+        d = os.path.join(args.out, f"{tag}_{name}")
+        log = os.path.join(args.out, f"{tag}_{name}.log")
+        print(f"[pmc_traffic] pass {name}: rocprofv3 {' '.join(flags)}", flush=True)
+        with open(log, "w") as lf:
+            subprocess.run(["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "--"] + cmd, stdout=lf, stderr=subprocess.STDOUT, env=env, cwd="/tmp", check=True)
+        js = [l for l in open(log) if l.startswith("{")]
+        if js:
+            bench_lines[name] = json.loads(js[-1])
+
+    # durations from the stats pass's kernel trace
+    dur = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(args.out, f"{tag}_stats", "*", "*_kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            fam, counting = family(r["Kernel_Name"])
+            if fam and not counting:
+                dur[fam].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+    for name in ("fetch", "write", "sq"):
+        for f in glob.glob(os.path.join(args.out, f"{tag}_{name}", "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                fam, counting = family(r["Kernel_Name"])
+                if fam and not counting:
+                    ctr[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kernels = {}
+    for fam in FAMILIES:
+        if fam not in dur and fam not in ctr:
+            continue
+        avg = {c: sum(v) / len(v) for c, v in ctr[fam].items()}
+        # a family may be launched more than once per launch set (traceKernel / shadeKernel with max_bounces > 1): per launch SET
+        per_set = 1
+        fetch, write = avg.get("FETCH_SIZE", 0.0) * 1024.0, avg.get("WRITE_SIZE", 0.0) * 1024.0
+        hit, miss = avg.get("TCC_HIT_sum", 0.0), avg.get("TCC_MISS_sum", 0.0)
+        k = {"launches_seen": len(dur.get(fam, [])), "launch_ms": round(sum(dur[fam]) / len(dur[fam]), 4) if dur.get(fam) else None,
+             "fetch_bytes_raw": fetch * per_set, "write_bytes": write * per_set, "hbm_bytes_per_launch": (2.0 * fetch + write) * per_set,
+             "l2_hit_pct": round(100.0 * hit / (hit + miss), 2) if hit + miss else None}
+        if avg.get("SQ_ACTIVE_INST_VALU"):
+            k["valu_lane_util"] = round(avg["SQ_THREAD_CYCLES_VALU"] / (64.0 * avg["SQ_ACTIVE_INST_VALU"]), 4)
+            wc = avg.get("SQ_WAVE_CYCLES", 0.0)
+            if wc:
+                k["wait_any_share"] = round(avg.get("SQ_WAIT_ANY", 0.0) / wc, 4)
+                k["wait_inst_share"] = round(avg.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
+                k["valu_inst_per_wave_cycle"] = round(avg.get("SQ_INSTS_VALU", 0.0) / wc, 4)
+        kernels[fam] = k
+    if "shadeKernel" in kernels and "accumulateKernel" in kernels:  # bench.py times them as one interval
+        a, b = kernels["shadeKernel"], kernels["accumulateKernel"]
+        kernels["shadeKernel"] = dict(a, hbm_bytes_per_launch=a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"], note="includes accumulateKernel's bytes")
+    out = {
+        "workload": args.workload, "frames_per_launch": args.frames, "source_sha": bench.kernel_source_sha(),
+        "command": "rocprofv3 <pass flags> --output-format csv -d <dir> -- " + " ".join(["python3", "bench.py"] + cmd[2:]),
+        "passes": {n: "rocprofv3 " + " ".join(f) for n, f in PASSES},
+        "definition": "hbm_bytes_per_launch = 2 * FETCH_SIZE * 1024 (gfx950 counts a 128-B request as 64 B; an upper bound for the traversal "
+                      "kernels' 16-B gathers) + WRITE_SIZE * 1024, averaged over the launches of the non-counting kernel variants, each of which "
+                      "traces `frames_per_launch` frames",
+        "kernels": kernels,
+        "bench_line_under_stats": bench_lines.get("stats"),
+    }
+    path = os.path.join(args.out, f"pmc_{tag}.json")
+    json.dump(out, open(path, "w"), indent=1)
+    lines = [f"# {out['command']}", f"# source_sha {out['source_sha']}  frames per launch {args.frames}",
+             f"{'kernel':24s} {'launches':>8s} {'launch_ms':>10s} {'FETCHx2 MiB':>12s} {'WRITE MiB':>10s} {'HBM GB/s':>9s} {'frac':>6s} {'L2hit%':>7s} {'lanes':>6s}"]
+    for fam, k in kernels.items():
+        ms = k["launch_ms"] or 0.0
+        gbs = k["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 if ms else 0.0
+        lines.append(f"{fam:24s} {k['launches_seen']:8d} {ms:10.3f} {2 * k['fetch_bytes_raw'] / 2**20:12.1f} {k['write_bytes'] / 2**20:10.1f} {gbs:9.1f} "
+                     f"{gbs / 8000.0:6.3f} {k['l2_hit_pct'] if k['l2_hit_pct'] is not None else 0:7.1f} {k.get('valu_lane_util', 0) or 0:6.3f}")
+    for f in glob.glob(os.path.join(args.out, f"{tag}_stats", "*", "*_kernel_stats.csv")):
+        lines.append("")
+        lines.append("# rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
+        lines.append(f"{'kernel':60s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}")
+        for r in csv.DictReader(open(f)):
+            lines.append(f"{r['Name'][:60]:60s} {int(r['Calls']):6d} {float(r['AverageNs']) / 1e3:10.1f} {int(r['MinNs']) / 1e3:10.1f} {int(r['MaxNs']) / 1e3:10.1f} {float(r['Percentage']):7.2f}")
+    open(os.path.join(args.out, f"pmc_{tag}.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
