@@ -1,5 +1,5 @@
 # Maintainer build without Python (python -c "import __graft_entry__ as g; g.build()" does the same, incrementally).
-#   make            libokrt.so (HIP, gfx950), libokrt_host.so (C++ host layer), examples/headless_host
+#   make            libokrt.so (HIP, gfx950), libokrt_host.so (C++ host layer), examples/headless_host, examples/headless_host_mgpu
 #   make oracle     the CPU checker used by tests/ (and the compiled reference pieces when /root/reference exists)
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
@@ -11,14 +11,14 @@ DEV_SRC  := $(wildcard $(PKG)/csrc/*.hip) $(wildcard $(PKG)/csrc/*.cpp)
 DEV_OBJ  := $(patsubst $(PKG)/csrc/%,$(PKG)/_build/%.o,$(DEV_SRC))
 HOST_SRC := $(wildcard $(PKG)/host/*.cpp)
 
-all: $(PKG)/libokrt.so $(PKG)/libokrt_host.so examples/headless_host
+all: $(PKG)/libokrt.so $(PKG)/libokrt_host.so examples/headless_host examples/headless_host_mgpu
 
 $(PKG)/_build/%.o: $(PKG)/csrc/% $(wildcard $(PKG)/csrc/*.h) include/okrt.h
 	@mkdir -p $(PKG)/_build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(PKG)/libokrt.so: $(DEV_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -ldl
 
 $(PKG)/libokrt_host.so: $(HOST_SRC) $(wildcard $(PKG)/host/*.h) include/okrt.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC)
@@ -27,11 +27,15 @@ examples/headless_host: examples/headless_host.cpp $(PKG)/libokrt.so $(PKG)/libo
 	$(CXX) -O2 -std=c++17 -ffp-contract=off $< -Iinclude -I$(PKG)/host -L$(PKG) -lokrt_host -lokrt -L/opt/rocm/lib -lamdhip64 \
 	    '-Wl,-rpath,$$ORIGIN/../$(PKG)' -Wl,-rpath,/opt/rocm/lib -o $@
 
+examples/headless_host_mgpu: examples/headless_host_mgpu.cpp $(PKG)/libokrt.so $(PKG)/libokrt_host.so
+	$(CXX) -O2 -std=c++17 -ffp-contract=off $< -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Iinclude -I$(PKG)/host -L$(PKG) -lokrt_host -lokrt \
+	    -L/opt/rocm/lib -lamdhip64 '-Wl,-rpath,$$ORIGIN/../$(PKG)' -Wl,-rpath,/opt/rocm/lib -o $@
+
 oracle:
 	$(MAKE) -C oracle all
 	@if [ -d /root/reference/source ]; then $(MAKE) -C oracle ref; fi
 
 clean:
-	rm -rf $(PKG)/_build $(PKG)/libokrt.so $(PKG)/libokrt_host.so examples/headless_host
+	rm -rf $(PKG)/_build $(PKG)/libokrt.so $(PKG)/libokrt_host.so examples/headless_host examples/headless_host_mgpu
 
 .PHONY: all oracle clean

@@ -83,6 +83,23 @@ def load_pmc(workload, frames_per_launch):
     return (best, None) if best else (None, why)
 
 
+def assert_single_hip_runtime():
+    """N > 1 shares device pointers and a stream between torch (RCCL collectives) and libokrt.so (kernels): both must
+    be bound to ONE libamdhip64 instance. Two mapped copies (libokrt.so loaded before torch, or an LD_LIBRARY_PATH that
+    resolves the soname differently) would each open the GPU on their own and the first cross-library pointer would
+    fault — fail here, with the paths, instead."""
+    paths = set()
+    try:
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                paths.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise SystemExit("bench.py: two HIP runtimes are mapped into this process (" + ", ".join(sorted(paths)) + "): import torch BEFORE "
+                         "loading libokrt.so, and do not point LD_LIBRARY_PATH at another ROCm; N > 1 needs one runtime instance")
+
+
 def usable_cpus():
     """Threads worth starting: the CPU count, cut down to the scheduler affinity and the cgroup quota (a one-GPU box
     shows 256 CPUs but grants its job a share of them)."""
@@ -290,6 +307,8 @@ def main():
     abi = importlib.import_module("gpu-raytracer_amd._abi")
     scenes = importlib.import_module("gpu-raytracer_amd.scenes")
     fns = abi.load_device_library()  # raises if libokrt.so is missing: no fallback
+    if world > 1:
+        assert_single_hip_runtime()
 
     builder, kwargs, W, H, wl_desc = WORKLOADS[args.workload]
     desc = getattr(scenes, builder)(**kwargs)

@@ -3,7 +3,7 @@
 // It links the host layer (okh::RayTracer, the mirror of source/Graphics/RayTracer.h) and the HIP device layer
 // (libokrt.so) through nothing but include/okrt.h — the literal "Application and Scene stay" drop-in, without a window.
 //
-//   headless_host <width> <height> <frames> <out.ppm> [device-builder]
+//   headless_host <width> <height> <frames> <out.png | out.ppm> [device-builder]
 //
 // Scene: the TestScene spheres of config 1 plus one small mesh (an octahedron with a checker texture), so that the
 // sphere, mesh, texture and accumulation paths are all live. tests/test_gpu_cpp_host.py builds the same scene through the
@@ -12,12 +12,15 @@
 #include <cstdlib>
 #include <vector>
 
+#include <string>
+
 #include "okrt.h"
+#include "png_writer.h"
 #include "raytracer_host.h"
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        std::fprintf(stderr, "usage: %s width height frames out.ppm [device-builder=0|1]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s width height frames out.png|out.ppm [device-builder=0|1]\n", argv[0]);
         return 2;
     }
     const uint32_t W = (uint32_t)std::atoi(argv[1]), H = (uint32_t)std::atoi(argv[2]), frames = (uint32_t)std::atoi(argv[3]);
@@ -93,11 +96,17 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "read_result: %s\n", okrt_last_error(rt.deviceContext()));
         return 1;
     }
-    FILE* out = std::fopen(argv[4], "wb");
-    if (!out) return 1;
-    std::fprintf(out, "P6\n%u %u\n255\n", W, H);
-    for (size_t i = 0; i < (size_t)W * H; ++i) std::fwrite(&rgba[4 * i], 1, 3, out);
-    std::fclose(out);
+    const std::string outPath = argv[4];
+    if (outPath.size() > 4 && outPath.compare(outPath.size() - 4, 4, ".png") == 0) {  // stbi_write_png("render.png", W, H, 4, data, W * 4)
+        std::string err;
+        if (!okh::writePng(outPath, W, H, rgba.data(), &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else {
+        FILE* out = std::fopen(argv[4], "wb");
+        if (!out) return 1;
+        std::fprintf(out, "P6\n%u %u\n255\n", W, H);
+        for (size_t i = 0; i < (size_t)W * H; ++i) std::fwrite(&rgba[4 * i], 1, 3, out);
+        std::fclose(out);
+    }
     okrt_build_info bi;
     okrt_get_build_info(rt.deviceContext(), &bi);
     std::printf("%ux%u, %u frames (numAccumulationFrames %u), structure: %u nodes / %u triangles built by %s\n", W, H, frames,

@@ -95,6 +95,15 @@ PRODUCT_ONLY = {
     "get_build_info": (C.c_int, [P, P]),
     "get_fast_structure": (C.c_int, [P, P, U32, P, U32]),
     "debug_kat": (C.c_int, [P, C.c_int, U32, P, U32, P, U32]),
+    "comm_unique_id": (C.c_int, [P]),
+    "comm_create": (C.c_int, [P, P, U32, U32, C.POINTER(P)]),
+    "comm_create_all": (C.c_int, [C.POINTER(P), U32, C.POINTER(P)]),
+    "comm_destroy": (C.c_int, [P]),
+    "comm_last_error": (C.c_char_p, [P]),
+    "mgpu_gather_accum": (C.c_int, [P, P, U32, P]),
+    "mgpu_gather_accum_all": (C.c_int, [C.POINTER(P), C.POINTER(P), U32, U32, P]),
+    "mgpu_read_gathered": (C.c_int, [P, P, P]),
+    "mgpu_deinterleave": (C.c_int, [P, P, U32, U32, U32, P]),
 }
 KAT_PCG_HASH, KAT_RANDOM_FLOAT, KAT_RAY_SPHERE, KAT_RAY_TRIANGLE, KAT_RAY_AABB, KAT_REFRACT, KAT_SAMPLE_TEXTURE, KAT_SAMPLE_ENV, KAT_CLOSEST_HIT, KAT_CLOSEST_HIT_FAST = range(10)
 KAT_RANDOM_VECTOR, KAT_REFLECTANCE, KAT_REFLECT_DIRECTION, KAT_TRANSPARENCY_BOUNCE, KAT_PRIMARY_RAY = range(10, 15)

@@ -14,6 +14,7 @@ REPO = os.path.dirname(PKG)
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall", "-Wno-class-memaccess"]
+DEVICE_LINK = ["-ldl"]  # okrt_mgpu.hip binds RCCL with dlopen
 
 
 def _newer(target, sources):
@@ -47,7 +48,7 @@ def build_device(force=False):
         list(pool.map(_run, jobs))
     objs = [os.path.join(objdir, os.path.basename(f) + ".o") for f in src]
     if force or jobs or _newer(out, objs):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + DEVICE_LINK)
     return out
 
 
@@ -67,15 +68,18 @@ def build_oracle():
 
 
 def build_examples(force=False):
-    """examples/headless_host: a C++ host linked against the host layer and the device layer (no Python in between)."""
-    src = os.path.join(REPO, "examples", "headless_host.cpp")
-    out = os.path.join(REPO, "examples", "headless_host")
-    deps = [src, os.path.join(PKG, "libokrt.so"), os.path.join(PKG, "libokrt_host.so")] + glob.glob(os.path.join(PKG, "host", "*.h"))
-    if force or _newer(out, deps):
-        _run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-ffp-contract=off", src, "-I" + os.path.join(REPO, "include"),
-              "-I" + os.path.join(PKG, "host"), "-L" + PKG, "-lokrt_host", "-lokrt", "-L/opt/rocm/lib", "-lamdhip64",
-              "-Wl,-rpath,$ORIGIN/../gpu-raytracer_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
-    return out
+    """examples/: C++ hosts linked against the host layer and the device layer (no Python in between)."""
+    outs = []
+    for name, extra in (("headless_host", []), ("headless_host_mgpu", ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"])):
+        src = os.path.join(REPO, "examples", name + ".cpp")
+        out = os.path.join(REPO, "examples", name)
+        deps = [src, os.path.join(PKG, "libokrt.so"), os.path.join(PKG, "libokrt_host.so")] + glob.glob(os.path.join(PKG, "host", "*.h"))
+        if force or _newer(out, deps):
+            _run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-ffp-contract=off", src] + extra + ["-I" + os.path.join(REPO, "include"),
+                  "-I" + os.path.join(PKG, "host"), "-L" + PKG, "-lokrt_host", "-lokrt", "-L/opt/rocm/lib", "-lamdhip64",
+                  "-Wl,-rpath,$ORIGIN/../gpu-raytracer_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+        outs.append(out)
+    return outs
 
 
 def build_all(force=False):

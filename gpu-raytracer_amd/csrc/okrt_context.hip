@@ -257,6 +257,17 @@ SceneView makeView(const okrt_ctx* c) {
 
 }  // namespace
 
+namespace okrt {
+okrt_status ctxFrame(okrt_ctx* c, CtxFrame* out) {
+    if (!c || !out) return OKRT_ERR_INVALID_ARG;
+    OKRT_FLUSH(c);
+    if (!c->W || !c->accum) return fail(c, OKRT_ERR_STATE, "multi-GPU gather before okrt_resize");
+    *out = CtxFrame{c->device, c->stream, c->accum, c->tile};
+    return OKRT_OK;
+}
+okrt_status ctxFail(okrt_ctx* c, okrt_status s, const std::string& msg) { return fail(c, s, msg); }
+}  // namespace okrt
+
 extern "C" {
 
 int okrt_abi_version(void) { return OKRT_ABI_VERSION; }
@@ -895,7 +906,13 @@ const okrt_api* okrt_get_api(void) {
                                  okrt_set_table,       okrt_set_textures,  okrt_set_envmap,   okrt_scale_texture_rgba8,
                                  okrt_resize,          okrt_set_tile,      okrt_tile_rows,    okrt_reset_accumulation,
                                  okrt_render,          okrt_synchronize,   okrt_read_result_rgba8, okrt_read_accum_f32x4,
-                                 okrt_set_option,      okrt_get_counters,  okrt_reset_counters, okrt_render_frames};
+                                 okrt_set_option,      okrt_get_counters,  okrt_reset_counters, okrt_render_frames,
+                                 okrt_write_accum_f32x4, okrt_bind_framebuffers, okrt_set_stream, okrt_commit,
+                                 okrt_get_build_info,  okrt_get_fast_structure, okrt_timer_begin, okrt_timer_end,
+                                 okrt_timer_elapsed_ms, okrt_last_render_ms, okrt_get_stage_ms, okrt_get_interval_ms,
+                                 okrt_debug_kat,       okrt_comm_unique_id, okrt_comm_create, okrt_comm_create_all,
+                                 okrt_comm_destroy,    okrt_comm_last_error, okrt_mgpu_gather_accum, okrt_mgpu_gather_accum_all,
+                                 okrt_mgpu_read_gathered, okrt_mgpu_deinterleave};
     return &api;
 }
 

@@ -39,6 +39,14 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
     uint32_t hitIdx = kInvalid, hitTri = kInvalid;
     uint32_t nNodes = 0, nTris = 0, nSeg = 0;
     bool exhausted = false;
+#ifdef OKRT_ITER_HIST  // diagnostic build: steps per ray, histogrammed into counters[2..9] (<=16, <=32, ... <=1024, more) and the maximum into [0] is left alone
+    uint32_t raySteps = 0;
+#define OKRT_HIST_STEP raySteps++;
+#define OKRT_HIST_DONE if (COUNT && counters) { uint32_t b_ = 0; while (b_ < 7 && raySteps > (16u << b_)) b_++; atomicAdd(&counters[2 + b_], 1ull); atomicMax(&counters[10], (unsigned long long)raySteps); } raySteps = 0;
+#else
+#define OKRT_HIST_STEP
+#define OKRT_HIST_DONE
+#endif
 
 #ifdef OKRT_STAMPS
     unsigned long long tRefill = 0, tInner = 0, tLeaf = 0, tStart = __builtin_amdgcn_s_memtime(), nRefill = 0, nIter = 0, laneIters = 0;
@@ -74,6 +82,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
                 stStream(&hb.tri[rayIdx], hitTri);
                 rayIdx = kInvalid;
+                OKRT_HIST_DONE
             }
             for (int round = 0; round < 2 && !exhausted; ++round) {
                 const unsigned long long need = __ballot(cur == kDone);
@@ -189,6 +198,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
 #endif
             const uint4 n0 = d0, n1 = d1, n2 = d2, n3 = d3;
             if (COUNT) nNodes++;
+            OKRT_HIST_STEP
             float tn[4];
             uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
             // slab test on the node's grid: t = (origin + q*step - o)/d = fma(q, step/d, (origin - o)/d)
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             if ((int)lane == __ffsll((long long)__ballot(true)) - 1) leafWave++;
 #endif
             if (COUNT) nTris++;
+            OKRT_HIST_STEP
             float bu = 0.f, bv = 0.f;
             const float t = rayAndTriangleEdges(ro, rdir, mk(__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)),
                                                 mk(__uint_as_float(d1.x), __uint_as_float(d1.y), __uint_as_float(d1.z)),
@@ -289,6 +300,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         atomicAdd(&counters[6], nodeWave); atomicAdd(&counters[7], nodeLane); atomicAdd(&counters[8], leafWave); atomicAdd(&counters[9], leafLane);
     }
 #endif
+#ifndef OKRT_ITER_HIST
     if (COUNT && counters) {
         uint32_t vals[3] = {nSeg, nNodes, nTris};
         const int slot[3] = {1, 10, 11};  // segments, fast_nodes, fast_tris
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
         }
     }
+#endif
 }
 
 // ---- packet traversal of camera rays --------------------------------------------------------------------------------
@@ -421,6 +434,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             }
 
         uint32_t sp = 0, cur = 0;  // wave-uniform
+#ifdef OKRT_ITER_HIST
+        uint32_t tileSteps = 0;
+#endif
 #ifdef OKRT_STAMPS
         pTiles++;
 #endif
@@ -434,6 +450,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 const uint4* np = nodes + (size_t)cur * 4;  // uniform address: scalar loads
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 if (COUNT) nNodes++;
+#ifdef OKRT_ITER_HIST
+                tileSteps++;
+#endif
                 const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
                 const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
                 const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
@@ -483,6 +502,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 for (uint32_t j = 0; j < count; ++j, tp += 3) {
                     const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
                     if (COUNT) nTris++;
+#ifdef OKRT_ITER_HIST
+                    tileSteps++;
+#endif
                     float bu = 0.f, bv = 0.f;
                     const float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
                     if (t > 0.f) {
@@ -502,6 +524,14 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             --sp;
             cur = stack[sp];  // same address in every lane (broadcast); written by lane 0 above
         }
+#ifdef OKRT_ITER_HIST
+        if (COUNT && counters && lane == 0) {
+            uint32_t b_ = 0;
+            while (b_ < 7 && tileSteps > (16u << b_)) b_++;
+            atomicAdd(&counters[2 + b_], 1ull);
+            atomicMax(&counters[10], (unsigned long long)tileSteps);
+        }
+#endif
         if (!FUSED) {
             if (valid) {
                 stStream(&hb.h[mine], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
@@ -563,9 +593,11 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) {
             if (v) atomicAdd(&counters[1], (unsigned long long)v);
+#ifndef OKRT_ITER_HIST
             // wave-uniform visit counts: every lane of the wave saw the same nodes / triangles
             atomicAdd(&counters[10], (unsigned long long)nNodes * 64ull);
             atomicAdd(&counters[11], (unsigned long long)nTris * 64ull);
+#endif
         }
     }
 }

@@ -1,5 +1,7 @@
 // okrt_kernels.h — launch interface between the context (okrt_context.hip) and the kernels.
 #pragma once
+#include <string>
+
 #include "okrt_device.h"
 
 namespace okrt {
@@ -28,5 +30,15 @@ void launchTileTextures(const void* src, void* dst, uint32_t slices, uint32_t W,
 
 // Known-answer probes of the device leaf functions (okrt_ref_kernel.hip, okrt_debug_kat).
 void launchKat(const SceneView& s, uint32_t op, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, hipStream_t stream);
+
+// What okrt_mgpu.hip needs of a context (okrt_context.hip owns the struct): pending frames executed, then the frame view.
+struct CtxFrame {
+    int device;
+    hipStream_t stream;
+    float4* accum;   // owned rows, packed
+    TileView tile;
+};
+okrt_status ctxFrame(okrt_ctx* c, CtxFrame* out);           // flushes deferred frames; OKRT_ERR_STATE before okrt_resize
+okrt_status ctxFail(okrt_ctx* c, okrt_status s, const std::string& msg);
 
 }  // namespace okrt

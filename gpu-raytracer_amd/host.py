@@ -269,6 +269,7 @@ def host_library():
             "okh_bvh_build": (U32, [P, U32, U32, U32, P, U32, P]),
             "okh_instance_matrices": (None, [F3, F3, F3, F3, F3]),
             "okh_cut_environment_cross": (U32, [P, U32, U32, P, U32]),
+            "okh_write_png": (C.c_int, [C.c_char_p, U32, U32, P]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)
@@ -460,6 +461,14 @@ class RayTracer:
             self.close()
         except Exception:
             pass
+
+
+def write_png(path, rgba8):
+    """Application::saveScreenshot's stbi_write_png through the host layer's own encoder (host/png_writer.cpp)."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 4
+    if not host_library().okh_write_png(os.fsencode(path), a.shape[1], a.shape[0], _ptr(a)):
+        raise OkrtError(f"cannot write {path}")
 
 
 def bvh_build(tris, max_leaf_triangles, max_depth):

@@ -5,6 +5,7 @@
 
 #include "obj_loader.h"
 #include "okrt_host.h"
+#include "png_writer.h"
 #include "raytracer_host.h"
 
 struct okh_resources { okh::ResourceManager rm; };
@@ -209,6 +210,10 @@ void okh_instance_matrices(const float pos[3], const float rot[3], const float s
     okh::Mat4 inv = okh::inverse(m);
     std::memcpy(outM, m.c, 64);
     std::memcpy(outInv, inv.c, 64);
+}
+
+int okh_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8) {
+    return path && okh::writePng(path, width, height, rgba8) ? 1 : 0;
 }
 
 uint32_t okh_cut_environment_cross(const uint8_t* img, uint32_t w, uint32_t h, uint8_t* faces, uint32_t cap) {

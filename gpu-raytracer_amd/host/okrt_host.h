@@ -81,6 +81,8 @@ int okh_resources_import_obj(okh_resources*, const char* filePath, float scale, 
 uint32_t okh_bvh_build(const float* tris9, uint32_t numTris, uint32_t maxLeafTriangles, uint32_t maxDepth,
                        void* nodes36, uint32_t nodeCapacity, uint32_t* triOrder);
 void okh_instance_matrices(const float pos[3], const float rotDeg[3], const float scale[3], float outM[16], float outInv[16]);
+/* "Save screenshot" (Application.cpp:661-674): 8-bit RGBA PNG, row 0 = top; 1 on success */
+int okh_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8);
 /* returns face side (0 = rejected); faces must hold 6*face*face*4 bytes */
 uint32_t okh_cut_environment_cross(const uint8_t* img, uint32_t w, uint32_t h, uint8_t* faces, uint32_t facesCapacity);
 

@@ -321,6 +321,36 @@ typedef enum okrt_kat {
 } okrt_kat;
 okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats);
 
+/* ---- multi-GPU: image-space split + RCCL gather over xGMI (new; the reference is single-GPU) ------------------------
+ * Every rank renders its stripes (okrt_set_tile(stripe_rows, rank, nranks)) with NO per-frame collective; whenever the
+ * host wants the whole frame, the packed float4 accumulation tiles are gathered to one root GPU — one ncclRecv per peer
+ * on the root, one ncclSend per peer, inside one ncclGroupStart/End, on the context's stream — and de-interleaved there
+ * into a full H x W frame. RCCL (librccl.so.1) is loaded on first use; a host that never calls these needs no RCCL.
+ *   one process per GPU:   rank 0: okrt_comm_unique_id -> distribute the 128 bytes out of band (MPI_Bcast, a file, a
+ *                          socket) -> every rank: okrt_comm_create(ctx, id, rank, nranks) -> okrt_mgpu_gather_accum
+ *   one process, n GPUs:   okrt_comm_create_all(ctxs, n, comms) -> okrt_mgpu_gather_accum_all(ctxs, comms, n, root, ...)
+ * A communicator of one rank never touches RCCL (the gather is a device-to-device copy). */
+#define OKRT_COMM_ID_BYTES 128
+typedef struct okrt_comm okrt_comm;
+okrt_status okrt_comm_unique_id(uint8_t out_id[OKRT_COMM_ID_BYTES]);
+okrt_status okrt_comm_create(okrt_ctx* ctx, const uint8_t id[OKRT_COMM_ID_BYTES], uint32_t rank, uint32_t nranks, okrt_comm** out_comm);
+/* ctxs[r] must live on n distinct devices; out_comms receives n communicators, rank r for ctxs[r]. */
+okrt_status okrt_comm_create_all(okrt_ctx* const* ctxs, uint32_t n, okrt_comm** out_comms);
+okrt_status okrt_comm_destroy(okrt_comm* comm);
+const char* okrt_comm_last_error(const okrt_comm* comm); /* comm == NULL: why the last create on this thread failed */
+/* Collective over the communicator. Every context must have the same frame size and the tile (stripe_rows, rank, nranks)
+ * of its rank. On `root`, full_frame_dev (device memory, H * W float4; NULL = a library-owned buffer, read it with
+ * okrt_mgpu_read_gathered) receives the whole accumulation, row 0 = top. Asynchronous on each context's stream. */
+okrt_status okrt_mgpu_gather_accum(okrt_ctx* ctx, okrt_comm* comm, uint32_t root, void* full_frame_dev);
+/* The same for n contexts driven by one thread (one RCCL group around all sends and receives). */
+okrt_status okrt_mgpu_gather_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* comms, uint32_t n, uint32_t root, void* full_frame_dev);
+/* Root only: copies the library-owned gathered frame (H * W * 4 floats) to the host; synchronises. */
+okrt_status okrt_mgpu_read_gathered(okrt_ctx* ctx, okrt_comm* comm, float* dst);
+/* The root-side step on its own: `tiles_dev` holds nranks packed tiles, tile r at r * tile_stride_rows rows of W float4
+ * (rows of stripes r, r + nranks, ... in order); writes the H x W frame to full_frame_dev. Uses the context's frame size. */
+okrt_status okrt_mgpu_deinterleave(okrt_ctx* ctx, const void* tiles_dev, uint32_t nranks, uint32_t stripe_rows, uint32_t tile_stride_rows,
+                                   void* full_frame_dev);
+
 /* ---- entry-point table -------------------------------------------------------------------------
  * The same entry points as a struct of function pointers, so a host written against this ABI
  * (gpu-raytracer_amd/host: the mirror of the reference's RayTracer class) binds to the device
@@ -346,6 +376,29 @@ typedef struct okrt_api {
     okrt_status (*get_counters)(okrt_ctx*, okrt_counters*);
     okrt_status (*reset_counters)(okrt_ctx*);
     okrt_status (*render_frames)(okrt_ctx*, const okrt_render_data*, uint32_t);
+    /* ABI 2: the rest of the surface. An implementation may leave entries it does not provide NULL (callers check). */
+    okrt_status (*write_accum_f32x4)(okrt_ctx*, const float*);
+    okrt_status (*bind_framebuffers)(okrt_ctx*, void*, void*);
+    okrt_status (*set_stream)(okrt_ctx*, void*);
+    okrt_status (*commit)(okrt_ctx*);
+    okrt_status (*get_build_info)(okrt_ctx*, okrt_build_info*);
+    okrt_status (*get_fast_structure)(okrt_ctx*, void*, uint32_t, void*, uint32_t);
+    okrt_status (*timer_begin)(okrt_ctx*);
+    okrt_status (*timer_end)(okrt_ctx*);
+    okrt_status (*timer_elapsed_ms)(okrt_ctx*, float*);
+    okrt_status (*last_render_ms)(okrt_ctx*, float*);
+    okrt_status (*get_stage_ms)(okrt_ctx*, float*, uint32_t*);
+    okrt_status (*get_interval_ms)(okrt_ctx*, float*, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+    okrt_status (*debug_kat)(okrt_ctx*, okrt_kat, uint32_t, const float*, uint32_t, float*, uint32_t);
+    okrt_status (*comm_unique_id)(uint8_t*);
+    okrt_status (*comm_create)(okrt_ctx*, const uint8_t*, uint32_t, uint32_t, okrt_comm**);
+    okrt_status (*comm_create_all)(okrt_ctx* const*, uint32_t, okrt_comm**);
+    okrt_status (*comm_destroy)(okrt_comm*);
+    const char* (*comm_last_error)(const okrt_comm*);
+    okrt_status (*mgpu_gather_accum)(okrt_ctx*, okrt_comm*, uint32_t, void*);
+    okrt_status (*mgpu_gather_accum_all)(okrt_ctx* const*, okrt_comm* const*, uint32_t, uint32_t, void*);
+    okrt_status (*mgpu_read_gathered)(okrt_ctx*, okrt_comm*, float*);
+    okrt_status (*mgpu_deinterleave)(okrt_ctx*, const void*, uint32_t, uint32_t, uint32_t, void*);
 } okrt_api;
 
 const okrt_api* okrt_get_api(void);

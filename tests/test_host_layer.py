@@ -187,3 +187,17 @@ def test_lights_reach_the_device_tables(oracle):
     rd = rt.render_data
     assert (rd.numDirLights, rd.numPointLights, rd.numSpotLights) == (1, 1, 1)
     rt.close()
+
+
+def test_png_writer_round_trips_through_an_independent_decoder(tmp_path):
+    """host/png_writer.cpp (the C++ side's stbi_write_png, Application.cpp:661-674) against PIL's decoder."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for (h, w) in [(1, 1), (7, 13), (180, 320), (300, 257)]:  # the last one spans several 65535-byte stored blocks
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        path = str(tmp_path / f"t{h}x{w}.png")
+        host.write_png(path, img)
+        back = np.asarray(Image.open(path))
+        assert back.shape == img.shape and np.array_equal(back, img)
+    with pytest.raises(abi.OkrtError):
+        host.write_png(str(tmp_path / "missing_dir" / "x.png"), np.zeros((2, 2, 4), np.uint8))

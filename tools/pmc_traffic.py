@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--passes", default="stats,fetch,write,sq")
     args = ap.parse_args()
     import bench
+    args.out = os.path.abspath(args.out)  # rocprofv3 runs from /tmp
     os.makedirs(args.out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     tag = f"{args.workload}_f{args.frames}"

@@ -45,8 +45,7 @@ def main():
         rt, scene, res = scenes.instantiate(build(), W, H, device=a.device)
     rt.ctx.set_option(abi.OPT_MAX_BOUNCES, a.bounces)
     rt.renderFrames(a.frames)
-    from PIL import Image
-    Image.fromarray(rt.ctx.read_result()).save(a.out)  # RGBA8, row 0 = top (stbi_write_png of the result target)
+    host.write_png(a.out, rt.ctx.read_result())  # RGBA8, row 0 = top (stbi_write_png of the result target)
     print(f"{a.out}: {W}x{H}, {rt.getNumAccumulationFrames()} frames")
 
 
