@@ -331,146 +331,161 @@ bool RayTracer::updateBuffers() {
     return true;
 }
 
-void RayTracer::refitOctTreeNode(OctTreeNode& node) {
-    node.boundingBox = AABB();
-    for (const EntityAABB& e : node.entities) {
-        const Entity& ent = m_pScene->get(e.entity);
-        if (ent.hasMesh || ent.hasSphere) {
-            node.boundingBox.growTo(e.aabb.min);
-            node.boundingBox.growTo(e.aabb.max);
-        }
+// ---- culling octree (reference RayTracer.cpp:503-788) ---------------------------------------------------------------
+// What the reference computes, restated on flat arrays: the scene's mesh and sphere entities become `items` (entity +
+// the box the reference files it under: the LOCAL mesh box, quirk Q22, or the sphere's world box); a cell holds indices
+// into `items`; cells are split depth-first from a LIFO work list, which fixes the cell numbering the shader's
+// firstChildIdx / numChildren rely on. The float arithmetic follows the reference operation for operation (the tables
+// must be bit-identical: tests/test_host_layer.py); the data structures and control flow are this file's own.
+namespace {
+
+struct SceneItem { uint32_t entity; AABB box; };
+struct OctCell {
+    AABB bounds;
+    std::vector<uint32_t> members;  // indices into the item array, in filing order
+    uint32_t child[8] = {INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT};
+    uint32_t depth = 0;
+};
+
+// Union of the members' boxes (refitOctTreeNode, :503-519; every item is a mesh or a sphere, so the reference's
+// component test is always true here).
+AABB fitToMembers(const std::vector<uint32_t>& members, const std::vector<SceneItem>& items) {
+    AABB fit;
+    for (uint32_t m : members) {
+        fit.growTo(items[m].box.min);
+        fit.growTo(items[m].box.max);
     }
+    return fit;
 }
+
+// Octant k of a cell: the cell shrunk to half size about its centre, then shifted by +-half of the shrunk extent per
+// axis. Sign table and operation order of :579-590,620-640 (sign bit pattern: x = !(k & 1), y = k & 2, z = !(k & 4)).
+AABB octantBounds(const AABB& cell, uint32_t k) {
+    const Vec3 centre = (cell.max + cell.min) * 0.5f;
+    AABB half;
+    half.max = (cell.max - centre) * 0.5f + centre;
+    half.min = (cell.min - centre) * 0.5f + centre;
+    const Vec3 shift = (half.max - half.min) * 0.5f;
+    const float sign[3] = {(k & 1u) ? -1.f : 1.f, (k & 2u) ? 1.f : -1.f, (k & 4u) ? -1.f : 1.f};
+    AABB out = half;
+    for (int a = 0; a < 3; ++a) {
+        out.max[a] += sign[a] * shift[a];
+        out.min[a] += sign[a] * shift[a];
+    }
+    return out;
+}
+
+}  // namespace
 
 bool RayTracer::createOctTree(const Scene& scene, uint32_t maxDepth, uint32_t maxLeafObjects) {
     m_pScene = &scene;
-    std::vector<OctTreeNode> nodes;
-    nodes.emplace_back();
-    {
-        OctTreeNode& root = nodes.back();
-        for (uint32_t id : scene.view([](const Entity& e) { return e.hasMesh; })) {  // :539-563
-            const Entity& ent = scene.get(id);
-            const Mesh& mesh = m_pResourceManager->meshes()[ent.mesh.meshID];
-            AABB meshBB = mesh.boundingBox;
-            Vec3 center = (meshBB.min + meshBB.max) * 0.5f;
-            Vec3 extents = (meshBB.min - meshBB.max) * 0.5f;  // negative extents, as in the reference (:546)
-            // DirectX::BoundingBox::GetCorners: Center + Extents * offset, offsets in g_BoxOffset order
-            static const float OFF[8][3] = {{-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}, {-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}};
-            Mat4 matrix = ent.transform.calculateMatrix();
-            for (int v = 0; v < 8; ++v) {
-                Vec3 corner{extents.x * OFF[v][0] + center.x, extents.y * OFF[v][1] + center.y, extents.z * OFF[v][2] + center.z};
-                float p[4];
-                mulPoint(matrix, corner, 1.f, p);
-                root.boundingBox.growTo(Vec3(p[0], p[1], p[2]));
-            }
-            root.entities.push_back({id, meshBB});  // the LOCAL mesh box (quirk Q22, :562)
+    std::vector<SceneItem> items;
+    std::vector<OctCell> cells(1);
+
+    // Root: bounds over the eight TRANSFORMED corners of every mesh box and over every sphere's box (:539-577). The
+    // corners come from DirectX::BoundingBox::GetCorners fed with centre and (min - max) / 2, i.e. NEGATIVE extents: the
+    // corner order below is g_BoxOffset's; with min/max accumulation the order only matters for NaNs.
+    for (uint32_t id : scene.view([](const Entity& e) { return e.hasMesh; })) {
+        const Entity& ent = scene.get(id);
+        const AABB& local = m_pResourceManager->meshes()[ent.mesh.meshID].boundingBox;
+        const Vec3 centre = (local.min + local.max) * 0.5f, extent = (local.min - local.max) * 0.5f;
+        const Mat4 toWorld = ent.transform.calculateMatrix();
+        for (uint32_t corner = 0; corner < 8; ++corner) {
+            // g_BoxOffset: x = -,+,+,-  y = -,-,+,+ (repeating), z = + for the first four corners, - for the rest
+            const float sx = ((corner & 3u) == 1u || (corner & 3u) == 2u) ? 1.f : -1.f, sy = (corner & 2u) ? 1.f : -1.f, sz = corner < 4u ? 1.f : -1.f;
+            const Vec3 p{extent.x * sx + centre.x, extent.y * sy + centre.y, extent.z * sz + centre.z};
+            float w[4];
+            mulPoint(toWorld, p, 1.f, w);
+            cells[0].bounds.growTo(Vec3(w[0], w[1], w[2]));
         }
-        for (uint32_t id : scene.view([](const Entity& e) { return e.hasSphere; })) {  // :565-577
-            const Entity& ent = scene.get(id);
-            float r = ent.sphere.radius;
-            AABB sphereBB;
-            sphereBB.min = Vec3(-r) + ent.transform.position;
-            sphereBB.max = Vec3(r) + ent.transform.position;
-            root.boundingBox.growTo(sphereBB.min);
-            root.boundingBox.growTo(sphereBB.max);
-            root.entities.push_back({id, sphereBB});
+        cells[0].members.push_back((uint32_t)items.size());
+        items.push_back({id, local});  // filed under its LOCAL box (Q22, :562)
+    }
+    for (uint32_t id : scene.view([](const Entity& e) { return e.hasSphere; })) {
+        const Entity& ent = scene.get(id);
+        AABB box;
+        box.min = Vec3(-ent.sphere.radius) + ent.transform.position;
+        box.max = Vec3(ent.sphere.radius) + ent.transform.position;
+        cells[0].bounds.growTo(box.min);
+        cells[0].bounds.growTo(box.max);
+        cells[0].members.push_back((uint32_t)items.size());
+        items.push_back({id, box});
+    }
+
+    std::vector<uint32_t> work = {0u};      // LIFO: the cell created last is split first (:592-612)
+    std::vector<uint32_t> candidates, taken;
+    std::vector<uint8_t> consumed;
+    while (!work.empty()) {
+        const uint32_t ci = work.back();
+        work.pop_back();
+        if (cells[ci].depth >= maxDepth || cells[ci].members.size() <= maxLeafObjects) continue;
+
+        // Only items clearly smaller than the cell may move down (area ratio < 0.75, :636-640); the count the
+        // "everything went into one octant" test uses is the cell's population BEFORE the split (:635).
+        const float cellArea = cells[ci].bounds.getArea();
+        const size_t population = cells[ci].members.size();
+        candidates.clear();
+        for (uint32_t m : cells[ci].members)
+            if (items[m].box.getArea() / cellArea < 0.75f) candidates.push_back(m);
+        consumed.assign(candidates.size(), 0);
+
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const AABB octant = octantBounds(cells[ci].bounds, k);
+            // an item goes to the FIRST octant it overlaps; once claimed it is gone for the later octants, also when
+            // the claim is then dropped because the octant swallowed the whole population (:656-675)
+            taken.clear();
+            for (size_t c = 0; c < candidates.size(); ++c)
+                if (!consumed[c] && AABB::intersects(octant, items[candidates[c]].box)) {
+                    consumed[c] = 1;
+                    taken.push_back(candidates[c]);
+                }
+            if (taken.empty() || taken.size() == population) continue;
+
+            std::vector<uint32_t>& stay = cells[ci].members;
+            stay.erase(std::remove_if(stay.begin(), stay.end(), [&](uint32_t m) { return std::find(taken.begin(), taken.end(), m) != taken.end(); }), stay.end());
+            const uint32_t childIdx = (uint32_t)cells.size();
+            cells.emplace_back();
+            cells[childIdx].members = taken;
+            cells[childIdx].bounds = fitToMembers(taken, items);  // children shrink to their contents (:697)
+            cells[childIdx].depth = cells[ci].depth + 1u;
+            cells[ci].child[k] = childIdx;
+            work.push_back(childIdx);
         }
     }
 
-    static const float CHILD_BBS_OFFSETS[8][3] = {{1, -1, 1}, {-1, -1, 1}, {1, 1, 1}, {-1, 1, 1}, {1, -1, -1}, {-1, -1, -1}, {1, 1, -1}, {-1, 1, -1}};  // :579-590
-    struct NodeStack { uint32_t parent, node, depth; };
-    std::stack<NodeStack> stack;
-    std::vector<EntityAABB> childEntities, childEntitiesPool;
-    stack.push({INVALID_UINT, 0u, 0u});
-
-    while (!stack.empty()) {  // :611-701
-        NodeStack sd = stack.top();
-        stack.pop();
-        if (sd.depth >= maxDepth || nodes[sd.node].entities.size() <= maxLeafObjects) continue;
-
-        AABB defaultChildBB = nodes[sd.node].boundingBox;
-        Vec3 bbCenter = (defaultChildBB.max + defaultChildBB.min) * 0.5f;
-        defaultChildBB.max = defaultChildBB.max - bbCenter;
-        defaultChildBB.min = defaultChildBB.min - bbCenter;
-        defaultChildBB.min = defaultChildBB.min * 0.5f;
-        defaultChildBB.max = defaultChildBB.max * 0.5f;
-        defaultChildBB.max = defaultChildBB.max + bbCenter;
-        defaultChildBB.min = defaultChildBB.min + bbCenter;
-
-        childEntitiesPool.clear();
-        float nodeBBArea = nodes[sd.node].boundingBox.getArea();
-        uint32_t totalChildren = (uint32_t)nodes[sd.node].entities.size();
-        for (int k = (int)nodes[sd.node].entities.size() - 1; k >= 0; k--)
-            if (nodes[sd.node].entities[k].aabb.getArea() / nodeBBArea < 0.75f) childEntitiesPool.push_back(nodes[sd.node].entities[k]);
-
-        Vec3 ext = (defaultChildBB.max - defaultChildBB.min) * 0.5f;
-        for (uint32_t i = 0; i < 8u; i++) {
-            AABB childBB = defaultChildBB;
-            for (int k = 0; k < 3; k++) {
-                childBB.max[k] += CHILD_BBS_OFFSETS[i][k] * ext[k];
-                childBB.min[k] += CHILD_BBS_OFFSETS[i][k] * ext[k];
-            }
-            childEntities.clear();
-            for (int k = (int)childEntitiesPool.size() - 1; k >= 0; k--) {
-                if (!AABB::intersects(childBB, childEntitiesPool[k].aabb)) continue;
-                childEntities.push_back(childEntitiesPool[k]);
-                childEntitiesPool.erase(childEntitiesPool.begin() + k);
-            }
-            if (childEntities.empty()) continue;
-            if (childEntities.size() == totalChildren) continue;  // (their pool entries stay consumed, as in the reference)
-            for (const EntityAABB& ce : childEntities) {
-                std::vector<EntityAABB>& pe = nodes[sd.node].entities;
-                for (size_t j = 0; j < pe.size(); j++)
-                    if (pe[j].entity == ce.entity) {
-                        pe.erase(pe.begin() + j);
-                        break;
-                    }
-            }
-            nodes.emplace_back();
-            uint32_t childIdx = (uint32_t)nodes.size() - 1;
-            nodes[sd.node].children[i] = childIdx;
-            nodes[childIdx].entities = childEntities;
-            refitOctTreeNode(nodes[childIdx]);
-            stack.push({sd.node, childIdx, sd.depth + 1u});
-        }
-    }
-    return loadOctTree(nodes);
-}
-
-bool RayTracer::loadOctTree(const std::vector<OctTreeNode>& nodes) {
-    m_octTreeNodes.assign(nodes.size(), GPU_OctTreeNode{});
+    // Flatten (:706-788): cells keep their numbers; a cell's children were created back to back, so (first, count)
+    // describes them; the instance table lists every cell's meshes in filing order, cell after cell.
+    m_octTreeNodes.assign(cells.size(), GPU_OctTreeNode{});
     m_gpuMeshes.clear();
-    for (uint32_t i = 0; i < (uint32_t)nodes.size(); i++) {
-        const OctTreeNode& node = nodes[i];
-        GPU_OctTreeNode& gpuNode = m_octTreeNodes[i];
-        std::memcpy(gpuNode.bbMin, &node.boundingBox.min, 12);
-        std::memcpy(gpuNode.bbMax, &node.boundingBox.max, 12);
-        for (uint32_t k = 0; k < 8u; k++) {  // :720-729
-            if (node.children[k] == INVALID_UINT) continue;
-            if (gpuNode.firstChildIdx == INVALID_UINT) gpuNode.firstChildIdx = node.children[k];
-            gpuNode.numChildren += 1;
-        }
-        uint32_t numMeshes = 0u;
-        for (const EntityAABB& e : node.entities) {  // :732-755
-            const Entity& ent = m_pScene->get(e.entity);
+    for (size_t i = 0; i < cells.size(); ++i) {
+        GPU_OctTreeNode& out = m_octTreeNodes[i];
+        std::memcpy(out.bbMin, &cells[i].bounds.min, 12);
+        std::memcpy(out.bbMax, &cells[i].bounds.max, 12);
+        for (uint32_t c : cells[i].child)
+            if (c != INVALID_UINT) {
+                if (!out.numChildren) out.firstChildIdx = c;
+                out.numChildren++;
+            }
+        out.meshesStartIdx = (uint32_t)m_gpuMeshes.size();
+        for (uint32_t m : cells[i].members) {
+            const Entity& ent = scene.get(items[m].entity);
             if (!ent.hasMesh) continue;
-            GPU_MeshComponent gpuMesh;
-            gpuMesh.triStart = m_meshDescs[ent.mesh.meshID].startIdx;
-            gpuMesh.triEnd = m_meshDescs[ent.mesh.meshID].endIdx;
-            const AABB& bb = m_pResourceManager->meshes()[ent.mesh.meshID].boundingBox;
-            std::memcpy(gpuMesh.bbMin, &bb.min, 12);
-            std::memcpy(gpuMesh.bbMax, &bb.max, 12);
-            Mat4 transformMatrix = transpose(ent.transform.calculateMatrix());  // :747-749
-            Mat4 inv = inverse(transformMatrix);
-            std::memcpy(gpuMesh.transformMatrix, transformMatrix.c, 64);
-            std::memcpy(gpuMesh.inverseTransformMatrix, inv.c, 64);
-            gpuMesh.material = ent.mesh.material;
-            gpuMesh.bvhNodeStartIdx = m_meshDescs[ent.mesh.meshID].bvhTreeStartIdx;
-            m_gpuMeshes.push_back(gpuMesh);
-            numMeshes++;
+            const MeshDesc& desc = m_meshDescs[ent.mesh.meshID];
+            const AABB& local = m_pResourceManager->meshes()[ent.mesh.meshID].boundingBox;
+            GPU_MeshComponent inst;
+            const Mat4 rows = transpose(ent.transform.calculateMatrix());  // uploaded transposed, inverse of the transposed (:747-749)
+            const Mat4 rowsInverse = inverse(rows);
+            std::memcpy(inst.transformMatrix, rows.c, 64);
+            std::memcpy(inst.inverseTransformMatrix, rowsInverse.c, 64);
+            inst.triStart = desc.startIdx;
+            inst.triEnd = desc.endIdx;
+            std::memcpy(inst.bbMin, &local.min, 12);
+            std::memcpy(inst.bbMax, &local.max, 12);
+            inst.material = ent.mesh.material;
+            inst.bvhNodeStartIdx = desc.bvhTreeStartIdx;
+            m_gpuMeshes.push_back(inst);
         }
-        gpuNode.meshesStartIdx = (uint32_t)m_gpuMeshes.size() - numMeshes;
-        gpuNode.meshesEndIdx = gpuNode.meshesStartIdx + numMeshes;
+        out.meshesEndIdx = (uint32_t)m_gpuMeshes.size();
     }
     m_renderData.numMeshes = 0u;  // :780
     return check(m_api->set_table(m_ctx, OKRT_TABLE_MESH, m_gpuMeshes.data(), sizeof(GPU_MeshComponent), (uint32_t)m_gpuMeshes.size()), "t7") &&

@@ -132,7 +132,7 @@ public:
     void shutdown();
 
     bool loadMeshAndBvhData(uint32_t maxDepth, uint32_t maxLeafTriangles);            // RayTracer.cpp:120-217
-    bool createOctTree(const Scene& scene, uint32_t maxDepth, uint32_t maxLeafObjects);  // RayTracer.cpp:523-704
+    bool createOctTree(const Scene& scene, uint32_t maxDepth, uint32_t maxLeafObjects);  // RayTracer.cpp:503-788 (build + flatten + upload)
     void setScene(const Scene& scene) { m_pScene = &scene; }
     bool render();                                                                    // RayTracer.cpp:219-260
     // `frames` consecutive render() calls with an unchanged scene and camera, handed to the device layer as one
@@ -170,16 +170,8 @@ public:
     const std::vector<uint8_t>& scaledTextures() const { return m_scaledTextures; }
 
 private:
-    struct EntityAABB { uint32_t entity; AABB aabb; };
-    struct OctTreeNode {
-        AABB boundingBox;
-        std::vector<EntityAABB> entities;
-        uint32_t children[8] = {INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT, INVALID_UINT};
-    };
     bool loadTextureData();                                                          // RayTracer.cpp:310-342
     bool loadEnvironmentMap(const uint8_t* img, uint32_t w, uint32_t h);             // RayTracer.cpp:344-432
-    bool loadOctTree(const std::vector<OctTreeNode>& nodes);                         // RayTracer.cpp:706-788
-    void refitOctTreeNode(OctTreeNode& node);                                        // RayTracer.cpp:503-519
     bool check(okrt_status s, const char* what);
 
     const okrt_api* m_api;

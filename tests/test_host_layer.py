@@ -201,3 +201,84 @@ def test_png_writer_round_trips_through_an_independent_decoder(tmp_path):
         assert back.shape == img.shape and np.array_equal(back, img)
     with pytest.raises(abi.OkrtError):
         host.write_png(str(tmp_path / "missing_dir" / "x.png"), np.zeros((2, 2, 4), np.uint8))
+
+
+# ---- hand-built octrees: cell numbering and instance order written out BY HAND from RayTracer.cpp:523-788 ---------------
+# (not from oracle/octree_oracle.py, which is the same author's restatement). Every mesh is an axis-aligned cube baked at
+# its position (identity transforms), so local boxes are world boxes. Rules used in the derivations:
+#   * views walk entities in REVERSE creation order, so the root files the LAST created entity first (:539-577);
+#   * AABB::intersects is strict: |centre distance| < sum of half extents on every axis (Utilities.h:86-91);
+#   * only items with area / cell area < 0.75 may move down (:639); area = xy + yz + zx of the extents (Utilities.h:78-82);
+#   * octant k is the half-size cell shifted by (x: - if k & 1, y: + if k & 2, z: - if k & 4) (:579-590);
+#   * an item goes to the first octant (k ascending) it overlaps; if an octant claims the whole population nothing is
+#     created and those items are spent for the remaining octants (:656-675);
+#   * children are fitted to their members (:697), split LIFO (:611-614), numbered in creation order.
+def _cube(centre, half):
+    c = np.asarray(centre, np.float64)
+    return scenes.box_mesh(c - half, c + half)
+
+
+def _octree_of(oracle, cubes, max_depth, max_leaf):
+    res = host.ResourceManager()
+    sc = host.Scene()
+    for centre, half in cubes:
+        sc.add_mesh(sc.create_entity(), res.add_mesh(*_cube(centre, half)))
+    sc.add_camera(sc.create_entity())
+    rt = host.RayTracer(api=oracle.api, fns=oracle.fns)
+    rt.initiate(8, 8, res)
+    rt.setScene(sc)
+    rt.createOctTree(sc, max_depth, max_leaf)
+    oct_t = rt.table(5)
+    inst = rt.table(7)
+    rt.close()
+    boxes = oct_t[:, :24].copy().view(np.float32).reshape(-1, 2, 3)
+    ids = oct_t[:, 24:].copy().view(np.uint32).reshape(-1, 6)  # meshesStart, meshesEnd, spheresStart, spheresEnd, firstChild, numChildren
+    inst_min = inst[:, 136:148].copy().view(np.float32).reshape(-1, 3) if len(inst) else np.zeros((0, 3), np.float32)
+    return boxes, ids, inst_min
+
+
+INV = 0xFFFFFFFF
+
+
+def test_hand_built_octree_one_level(oracle):
+    """Creation order: e0 cube at (-10,-10,-10), e1 at (10,10,10), e2 at (10,-10,10) (half 0.5), e3 the cube [-12,12]^3.
+    Root files [e3, e2, e1, e0]; bounds [-12,12]^3, area 3*24^2. e3's ratio is 1 -> it stays. Octants (half cell [-6,6]^3
+    shifted by 6): k=0 (+,-,+) takes e2; k=2 (+,+,+) takes e1; k=5 (-,-,-) takes e0; each is 1 of a population of 4, so
+    cells 1, 2, 3 are created in that order and fitted to their cube. Instances: cell 0 [e3], then e2, e1, e0."""
+    boxes, ids, inst_min = _octree_of(oracle, [((-10, -10, -10), 0.5), ((10, 10, 10), 0.5), ((10, -10, 10), 0.5), ((0, 0, 0), 12.0)], 2, 1)
+    assert ids[:, [0, 1, 4, 5]].tolist() == [[0, 1, 1, 3], [1, 2, INV, 0], [2, 3, INV, 0], [3, 4, INV, 0]]
+    assert np.array_equal(boxes[0], [[-12, -12, -12], [12, 12, 12]])
+    assert np.array_equal(boxes[1], [[9.5, -10.5, 9.5], [10.5, -9.5, 10.5]])    # e2
+    assert np.array_equal(boxes[2], [[9.5, 9.5, 9.5], [10.5, 10.5, 10.5]])      # e1
+    assert np.array_equal(boxes[3], [[-10.5, -10.5, -10.5], [-9.5, -9.5, -9.5]])  # e0
+    assert inst_min.tolist() == [[-12, -12, -12], [9.5, -10.5, 9.5], [9.5, 9.5, 9.5], [-10.5, -10.5, -10.5]]
+
+
+def test_hand_built_octree_two_levels_first_octant_wins(oracle):
+    """Creation order: A = [-1,1]^3, B cube at (5,-5,5), C at (6,-6,6), D at (-6,6,-6) (half 0.5). Root files [D, C, B, A],
+    bounds [-6.5,6.5]^3 (area 507; every ratio is tiny), octants of half 3.25. k=0 (+,-,+), centre (3.25,-3.25,3.25):
+    C (distance 2.75 < 3.75), B (1.75) and A (3.25 < 4.25) overlap it -> cell 1 = [C, B, A] (3 of 4), although A also
+    overlaps the other seven. k=7 (-,+,-) takes D -> cell 2. LIFO: cell 2 (one member) is popped first and left alone;
+    cell 1 (depth 1, bounds x[-1,6.5] y[-6.5,1] z[-1,6.5], centre (2.75,-2.75,2.75), octant half 1.875) splits: k=0, centre
+    (4.625,-4.625,4.625), takes C (1.375 < 2.375) and B (0.375) but not A (4.625 > 2.875) -> cell 3 = [C, B]; A meets
+    none of k=1..6 (always one axis at distance 4.625) and k=7, centre (0.875,-0.875,0.875) -> cell 4 = [A]. Depth 2 stops.
+    Instances in cell order: cells 0 and 1 are empty, cell 2 [D], cell 3 [C, B], cell 4 [A]."""
+    boxes, ids, inst_min = _octree_of(oracle, [((0, 0, 0), 1.0), ((5, -5, 5), 0.5), ((6, -6, 6), 0.5), ((-6, 6, -6), 0.5)], 2, 1)
+    assert ids[:, [0, 1, 4, 5]].tolist() == [[0, 0, 1, 2], [0, 0, 3, 2], [0, 1, INV, 0], [1, 3, INV, 0], [3, 4, INV, 0]]
+    assert np.array_equal(boxes[0], [[-6.5, -6.5, -6.5], [6.5, 6.5, 6.5]])
+    assert np.array_equal(boxes[1], [[-1, -6.5, -1], [6.5, 1, 6.5]])
+    assert np.array_equal(boxes[2], [[-6.5, 5.5, -6.5], [-5.5, 6.5, -5.5]])
+    assert np.array_equal(boxes[3], [[4.5, -6.5, 4.5], [6.5, -4.5, 6.5]])
+    assert np.array_equal(boxes[4], [[-1, -1, -1], [1, 1, 1]])
+    assert inst_min.tolist() == [[-6.5, 5.5, -6.5], [5.5, -6.5, 5.5], [4.5, -5.5, 4.5], [-1, -1, -1]]  # D, C, B, A
+
+
+def test_hand_built_octree_whole_population_in_one_octant_is_not_split(oracle):
+    """P = [0,2]^3, Q = [1,3]^3 (creation order P, Q -> filed [Q, P]); root [0,3]^3, area 27, both ratios 12/27 < 0.75.
+    Octant k=0 (+,-,+) = x[1.5,3] y[0,1.5] z[1.5,3], centre (2.25,0.75,2.25), half 0.75: P (centre 1: distances 1.25, 0.25,
+    1.25 < 1.75) and Q (centre 2: 0.25, 1.25, 0.25) both overlap it -> the claim equals the population (2), nothing is
+    created, and both are spent: the root stays a leaf of two although max_leaf is 1 (:671-675)."""
+    boxes, ids, inst_min = _octree_of(oracle, [((1, 1, 1), 1.0), ((2, 2, 2), 1.0)], 3, 1)
+    assert ids[:, [0, 1, 4, 5]].tolist() == [[0, 2, INV, 0]]
+    assert np.array_equal(boxes[0], [[0, 0, 0], [3, 3, 3]])
+    assert inst_min.tolist() == [[1, 1, 1], [0, 0, 0]]  # Q, P
