@@ -53,6 +53,8 @@ public:
     // positions: numTris*9 floats; info: numTris*33 floats (TriangleInfo layout) or nullptr (zeros).
     uint32_t addMesh(const float* positions, const float* info, uint32_t numTris);
     uint32_t addTexture(const uint8_t* rgba8, uint32_t width, uint32_t height);
+    // an importer's own box for a mesh (Importer.cpp:52-53) instead of the one addMesh computed from the vertices
+    void setMeshBoundingBox(uint32_t meshId, const AABB& box) { m_meshes[meshId].boundingBox = box; }
     const std::vector<Mesh>& meshes() const { return m_meshes; }
     const std::vector<Texture>& textures() const { return m_textures; }
 private:

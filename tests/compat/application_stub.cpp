@@ -1,0 +1,123 @@
+// application_stub.cpp — a windowless stand-in for the reference's Application that makes the SAME calls, in the same
+// order and with the same argument types, against the reference's own Scene / Entity / Components / ResourceManager
+// headers and the facade classes of gpu-raytracer_amd/host/compat (RayTracer, GPUStorage, RenderTexture, Okay::):
+//   Application::Application   Application.cpp:25-52    initiateDX11, m_target.initiate, loadMeshesAsEntities,
+//                                                        m_rayTracer.initiate(m_target, m_resourceManager, envPath), setScene
+//   Application::run           Application.cpp:61-128   camera entity, createOctTree, render() once per frame
+//   "Rebuild BVH tree"         Application.cpp:408-411  loadMeshAndBvhData(depth, leaf triangles)
+//   component edit             Application.cpp:312-317  resetAccumulation + createOctTree
+//   Application::saveScreenshot Application.cpp:661-674 *m_target.getBuffer(), GetDesc, getCPUTextureData, stbi_write_png
+// Built and run only where the reference checkout exists (tests/test_compat_kit.py); the device layer is whatever
+// okrt_api table the shared library named on the command line exports (the CPU checker in the container).
+//
+//   application_stub <api-library.so> <api-symbol> <scene.obj> <env-cross.png|-> <width> <height> <frames> <out.png>
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "DirectX/DX11.h"
+#include "DirectX/RenderTexture.h"
+#include "Graphics/RayTracer.h"
+#include "Graphics/ResourceManager.h"
+#include "Scene/Components.h"
+#include "Scene/Entity.h"
+#include "Scene/Scene.h"
+
+#define sprintf_s snprintf  // the vendored stb_image_write.h is the MSVC flavour (same argument order)
+#define STB_IMAGE_WRITE_IMPLEMENTATION
+#include "stb/stb_image_write.h"
+
+struct Application {
+    RenderTexture m_target;
+    ResourceManager m_resourceManager;
+    Scene m_scene;
+    RayTracer m_rayTracer;
+    uint32_t m_maxCullingTreeDepth = 2u, m_maxCullingTreeLeafEntities = 50u;  // Application.h:30-31
+    uint32_t m_maxBvhLeafTriangles = 5u, m_maxBvhDepth = 30u;                // Application.h:33-34
+
+    void loadMeshesAsEntities(std::string_view filePath, std::string_view texturesPath, float scale) {  // Application.cpp:131-152
+        std::vector<ResourceManager::ObjectDecription> objectDescriptions;
+        if (!m_resourceManager.importAssets(filePath, objectDescriptions, texturesPath, scale)) {
+            std::fprintf(stderr, "importAssets failed\n");
+            std::exit(1);
+        }
+        for (ResourceManager::ObjectDecription& objectDesc : objectDescriptions) {
+            Entity entity = m_scene.createEntity();
+            MeshComponent& meshComp = entity.addComponent<MeshComponent>();
+            meshComp.meshID = objectDesc.meshId;
+            meshComp.material.albedo.textureId = objectDesc.albedoTextureId;
+            meshComp.material.roughness.textureId = objectDesc.rougnessTextureId;
+            meshComp.material.metallic.textureId = objectDesc.metallicTextureId;
+            meshComp.material.specular.textureId = objectDesc.specularTextureId;
+            meshComp.material.normalMapIdx = objectDesc.normalTextureId;
+        }
+    }
+
+    void saveScreenshot(const char* path) {  // Application.cpp:661-674
+        ID3D11Texture2D* sourceBuffer = *m_target.getBuffer();
+        D3D11_TEXTURE2D_DESC desc{};
+        sourceBuffer->GetDesc(&desc);
+        void* textureData = nullptr;
+        Okay::getCPUTextureData(sourceBuffer, &textureData);
+        stbi_write_png(path, (int)desc.Width, (int)desc.Height, 4, textureData, desc.Width * 4);
+        unsigned char* bytes = (unsigned char*)textureData;
+        OKAY_DELETE_ARRAY(bytes);
+    }
+};
+
+int main(int argc, char** argv) {
+    if (argc < 9) {
+        std::fprintf(stderr, "usage: %s api.so api_symbol scene.obj env.png|- width height frames out.png\n", argv[0]);
+        return 2;
+    }
+    void* lib = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { std::fprintf(stderr, "%s\n", dlerror()); return 1; }
+    typedef const okrt_api* (*GetApi)(void);
+    GetApi getApi = (GetApi)dlsym(lib, argv[2]);
+    if (!getApi) { std::fprintf(stderr, "%s lacks %s\n", argv[1], argv[2]); return 1; }
+    okay_compat::setDeviceApi(getApi());
+    const uint32_t width = (uint32_t)std::atoi(argv[5]), height = (uint32_t)std::atoi(argv[6]), frames = (uint32_t)std::atoi(argv[7]);
+    const std::string env = std::string(argv[4]) == "-" ? "" : argv[4];
+
+    Application app;
+    Okay::initiateDX11();                                                   // Application.cpp:25 (through Window / initiateImGui in the reference)
+    app.m_target.initiate(width, height, TextureFormat::F_8X4);             // :28
+    app.loadMeshesAsEntities(argv[3], "", 1.f);                             // :44
+    app.m_rayTracer.initiate(app.m_target, app.m_resourceManager, env);     // :48
+    app.m_rayTracer.setScene(app.m_scene);                                  // :49
+    if (!app.m_rayTracer.lastError().empty()) { std::fprintf(stderr, "initiate: %s\n", app.m_rayTracer.lastError().c_str()); return 1; }
+
+    Entity camera = app.m_scene.createEntity();                             // :63-66
+    camera.addComponent<Camera>(80.f, 0.1f);
+    camera.getComponent<Transform>().position = glm::vec3(0.f, 2.f, 7.f);
+    camera.getComponent<Transform>().rotation = glm::vec3(10.f, 180.f, 0.f);
+    Entity light = app.m_scene.createEntity();
+    light.addComponent<PointLight>().intensity = 2.f;
+    light.getComponent<Transform>().position = glm::vec3(2.f, 6.f, 3.f);
+    Entity ball = app.m_scene.createEntity();                               // a Sphere entity (kernel path live, Q18)
+    ball.addComponent<Sphere>().radius = 0.8f;
+    ball.getComponent<Sphere>().material.albedo.colour = glm::vec3(0.9f, 0.2f, 0.2f);
+    ball.getComponent<Transform>().position = glm::vec3(-2.5f, 0.8f, 1.f);
+
+    app.m_rayTracer.createOctTree(app.m_scene, app.m_maxCullingTreeDepth, app.m_maxCullingTreeLeafEntities);  // :104
+    for (uint32_t f = 0; f < frames / 2; ++f) app.m_rayTracer.render();     // :117, once per frame of the main loop
+
+    app.m_rayTracer.loadMeshAndBvhData(8u, 2u);                             // "Rebuild BVH tree", :408-411
+    app.m_rayTracer.resetAccumulation();                                    // a component edit, :312-317
+    app.m_rayTracer.createOctTree(app.m_scene, app.m_maxCullingTreeDepth, app.m_maxCullingTreeLeafEntities);
+    app.m_rayTracer.getDOFStrength() = 0.05f;                               // ImGui DragFloat on the reference it returns
+    app.m_rayTracer.getDOFDistance() = 6.f;
+    for (uint32_t f = 0; f < frames; ++f) app.m_rayTracer.render();
+    if (!app.m_rayTracer.lastError().empty()) { std::fprintf(stderr, "render: %s\n", app.m_rayTracer.lastError().c_str()); return 1; }
+
+    app.saveScreenshot(argv[8]);
+    std::printf("frames %u meshes %zu triangles %u octree nodes %zu bvh nodes %zu\n", app.m_rayTracer.getNumAccumulationFrames(),
+                app.m_rayTracer.getMeshDescriptors().size(), app.m_rayTracer.getTrianglesPos().getCapacity(), app.m_rayTracer.getOctTreeNodes().size(),
+                app.m_rayTracer.getBvhTreeNodes().size());
+    app.m_rayTracer.shutdown();                                             // Application::~Application, :54-62
+    Okay::shutdownDX11();
+    return 0;
+}
