@@ -34,6 +34,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "okrt_fast_internal.h"
 
@@ -61,6 +62,12 @@ bool devAlloc(T** p, size_t n, std::string& err) {
 constexpr uint32_t kMaxSegments = 66;                       // max_bounces <= 64
 constexpr uint32_t kCursorBase = kMaxSegments * kShards * kCursorStride;
 constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorStride;
+// tail-drain counters of segment b (TailView): kShards exit counters, then continuation count / entry cursor / drain cursor
+constexpr uint32_t kTailStride = (kShards + 8) * kCursorStride;
+constexpr uint32_t kTailBase = kCountWords;
+constexpr uint32_t kAllCountWords = kTailBase + kMaxSegments * kTailStride;
+constexpr uint32_t kContinuations = 1u << 17;       // continuation headers per segment launch (32 B each)
+constexpr uint32_t kContinuationEntries = 1u << 22; // stack entries in the pool (8 B each)
 
 struct FastScene {
     DeviceArray<uint4> nodes;   // 4 x uint4 per Node4Q
@@ -82,6 +89,11 @@ struct FastScene {
     okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
     float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
     size_t radianceCap = 0;
+    uint4* tailHeaders = nullptr;  // tail drain (TailView): continuation headers and the stack-entry pool, reused by every segment
+    uint2* tailEntries = nullptr;
+    TailConst* tailConst = nullptr;  // device copy of the per-scene tail parameters
+    uint32_t tailPercent = 97;     // (-DOKRT_TAIL_DRAIN=1 builds) export once this share of a launch's waves has exited; OKRT_TAIL_PERCENT
+    uint32_t tailUploaded = ~0u;   // the exportAt value tailConst holds
 };
 
 bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& tables, uint32_t builder, hipStream_t stream, std::string& err) {
@@ -130,7 +142,14 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
         if (!devAlloc(&fs.overflow, (size_t)fs.traceBlocks * kTraceThreads * cap, err)) return false;
         fs.overflowCap = cap;
     }
-    if (!fs.counts && !devAlloc(&fs.counts, kCountWords, err)) return false;
+    if (!fs.counts && !devAlloc(&fs.counts, kAllCountWords, err)) return false;
+    if (OKRT_TAIL_DRAIN) {
+        if (getenv("OKRT_TAIL_PERCENT")) fs.tailPercent = (uint32_t)atoi(getenv("OKRT_TAIL_PERCENT"));
+        if (!fs.tailHeaders && !devAlloc(&fs.tailHeaders, (size_t)kContinuations * 2, err)) return false;
+        if (!fs.tailEntries && !devAlloc(&fs.tailEntries, kContinuationEntries, err)) return false;
+        if (!fs.tailConst && !devAlloc(&fs.tailConst, 1, err)) return false;
+    }
+    fs.tailUploaded = ~0u;
     return true;
 }
 
@@ -183,7 +202,8 @@ void fastDestroy(FastScene* fs) {
     fs->nodes.release();
     fs->tris.release();
     if (fs->builder) deviceBuilderDestroy(fs->builder);
-    for (void* p : {(void*)fs->rdDev, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance})
+    for (void* p : {(void*)fs->rdDev, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance, (void*)fs->tailHeaders,
+                    (void*)fs->tailEntries, (void*)fs->tailConst})
         if (p) hipFree(p);
     for (RayQueue& q : fs->q)
         for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
@@ -239,7 +259,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         return LaunchStatus::Invalid;
     }
     if (!fs.rdDev && !devAlloc(&fs.rdDev, 1, err)) return LaunchStatus::OutOfMemory;
-    if (hipFailed(hipMemsetAsync(fs.counts, 0, (size_t)kCountWords * sizeof(uint32_t), stream), "hipMemsetAsync(queue counters)")) return LaunchStatus::Device;
+    if (hipFailed(hipMemsetAsync(fs.counts, 0, (size_t)kAllCountWords * sizeof(uint32_t), stream), "hipMemsetAsync(queue counters)")) return LaunchStatus::Device;
     FastView fv{fs.nodes.p, fs.tris.p, fs.overflow, fs.overflowCap};
     const dim3 tg(fs.traceBlocks);
     const dim3 sg((unsigned)(items / 256));
@@ -251,13 +271,30 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     };
     static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
     static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
-    static const uint32_t envNodeMin = getenv("OKRT_FAST_NODE_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_NODE_MIN")) : 32u;
-    static const uint32_t envTriMin = getenv("OKRT_FAST_TRI_MIN") ? (uint32_t)atoi(getenv("OKRT_FAST_TRI_MIN")) : 24u;
-    static const uint32_t envRefill = getenv("OKRT_FAST_REFILL") ? (uint32_t)atoi(getenv("OKRT_FAST_REFILL")) : (uint32_t)kRefillBelow;
+    // (the refill threshold and the two step-block thresholds are compile-time constants of the trace kernel now:
+    // -DOKRT_REFILL_BELOW / -DOKRT_NODE_MIN / -DOKRT_TRI_MIN with tools/build_variant.sh; three fewer SGPRs live in its loop)
+    const uint32_t envNodeMin = kNodeMin, envTriMin = kTriMin, envRefill = (uint32_t)kRefillBelow;
     auto shards = [&](uint32_t b, bool camera) {
         return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, envNodeMin, envTriMin, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
                          fs.counts + kCursorBase + b * kShards * kCursorStride};
     };
+    // tail drain: on when the drain kernel's shared stack is certain to hold a traversal of this tree (depth-first bound
+    // 3 * depth + 4, twice over); a wave starts exporting once `tailPercent` % of the launch's waves have exited
+    const uint32_t traceWaves = (uint32_t)fs.traceBlocks * (kTraceThreads / 64);
+    const bool tailOk = OKRT_TAIL_DRAIN && fs.tailPercent > 0 && 2u * (3u * fs.maxDepth + 8u) <= kDrainStack;
+    const uint32_t exportAt = tailOk ? std::max<uint32_t>((uint32_t)(((uint64_t)traceWaves * fs.tailPercent + 99) / 100), 1u) : 0u;
+    if (tailOk && fs.tailUploaded != exportAt) {  // (scene build or option change: rare, synchronous)
+        static const uint32_t envLanes = getenv("OKRT_TAIL_LANES") ? (uint32_t)atoi(getenv("OKRT_TAIL_LANES")) : 0u;
+        static const uint32_t envIters = getenv("OKRT_TAIL_ITERS") ? (uint32_t)atoi(getenv("OKRT_TAIL_ITERS")) : 0u;
+        const TailConst tc{fs.tailHeaders, fs.tailEntries, kContinuations, kContinuationEntries, exportAt, envLanes, envIters, 0u};
+        if (hipFailed(hipStreamSynchronize(stream), "hipStreamSynchronize") || hipFailed(hipMemcpy(fs.tailConst, &tc, sizeof(tc), hipMemcpyHostToDevice), "hipMemcpy(tail)"))
+            return LaunchStatus::Device;
+        fs.tailUploaded = exportAt;
+    }
+    auto tail = [&](uint32_t b) { return TailView{tailOk ? fs.counts + kTailBase + b * kTailStride : nullptr, fs.tailConst}; };
+    static const bool dbgNoDrain = getenv("OKRT_DBG_NO_DRAIN") != nullptr;
+    static const int envDrainBlocks = getenv("OKRT_TAIL_BLOCKS") ? atoi(getenv("OKRT_TAIL_BLOCKS")) : 16;
+    const dim3 dg((unsigned)(dbgNoDrain ? 0 : fs.cus * envDrainBlocks));  // drain: one wave per block, 8 per CU; idle ones leave at once
     mark();
     static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
@@ -277,7 +314,11 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
         launchGenerate(sg, stream, rd, t, fs.q[0], perFrame, frames);
         if (packet) launchPacket(cnt, false, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
-        else launchTrace(cnt, tg, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals);
+        else {
+            const TailView tv = tail(0);
+            launchTrace(cnt, tg, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, tv);
+            if (tv.ctr && dg.x) launchDrain(dg, stream, fv, fs.q[0], fs.hb, tv, fs.maxDepth);
+        }
         mark();
         launchShade(true, cnt, sg, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result,
                     radiance, counters);
@@ -288,7 +329,9 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     for (uint32_t b = 1; b <= lastBounce; ++b) {
         RayQueue& qin = fs.q[b & 1];
         RayQueue& qout = fs.q[(b + 1) & 1];
-        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals);
+        const TailView tv = tail(b);
+        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals, tv);
+        if (tv.ctr && dg.x) launchDrain(dg, stream, fv, qin, fs.hb, tv, fs.maxDepth);
         mark();
         launchShade(false, cnt, sg, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum,
                     result, radiance, counters);

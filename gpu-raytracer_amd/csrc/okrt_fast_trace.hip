@@ -11,7 +11,7 @@ namespace {
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
                                                             HitBuffer hb, ShardView sv, uint32_t cameraFrames,
-                                                            unsigned long long* counters, unsigned long long* rayTotals) {
+                                                            unsigned long long* counters, unsigned long long* rayTotals, TailView tv) {
     // (ref, entry distance) pairs, [entry][thread]; row kLdsStack is a dummy target for predicated-off pushes
     __shared__ uint2 sStack[kLdsStack + 1][kTraceThreads];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -39,6 +39,10 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
     uint32_t hitIdx = kInvalid, hitTri = kInvalid;
     uint32_t nNodes = 0, nTris = 0, nSeg = 0;
     bool exhausted = false;
+#if OKRT_TAIL_DRAIN
+    uint32_t tailIter = 0;        // iterations since this wave ran out of work (wave-uniform)
+    bool tailOpen = tv.ctr != nullptr;
+#endif
 #ifdef OKRT_ITER_HIST  // diagnostic build: steps per ray, histogrammed into counters[2..9] (<=16, <=32, ... <=1024, more) and the maximum into [0] is left alone
     uint32_t raySteps = 0;
 #define OKRT_HIST_STEP raySteps++;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
 #endif
         // ---- refill: lanes whose traversal ended store their hit and take the next rays --------
         const unsigned long long idle = __ballot(cur == kDone);
-        if ((uint32_t)__popcll(~idle) < sv.refillBelow) {
+        if ((uint32_t)__popcll(~idle) < (uint32_t)kRefillBelow) {
             OKRT_T0
 #ifdef OKRT_STAMPS
             nRefill++;
@@ -166,6 +170,44 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             if (__ballot(rayIdx != kInvalid) == 0ull) break;  // queues drained and every lane idle
         }
 
+#if OKRT_TAIL_DRAIN
+        // ---- tail: out of work and nearly alone on the GPU -> hand the unfinished rays to the drain kernel -------------
+        if (exhausted && tailOpen && (++tailIter & 3u) == 0u) {
+            uint32_t gone = lane < kShards ? __hip_atomic_load(&tv.ctr[lane * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            gone += __shfl_xor(gone, 1, 64);
+            gone += __shfl_xor(gone, 2, 64);
+            gone += __shfl_xor(gone, 4, 64);
+            const TailConst tc = *tv.tc;
+            const bool live = cur != kDone;
+            const unsigned long long em = __ballot(live);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane(gone) >= tc.exportAt || (uint32_t)__popcll(em) <= tc.maxLanes || (tc.afterIters && tailIter >= tc.afterIters)) {
+                if (em) {
+                    uint32_t* cont = tv.ctr + kShards * kCursorStride;
+                    const uint32_t n = sp + 1u;  // the stack plus the reference in hand
+                    uint32_t slot0 = 0;
+                    if (lane == (uint32_t)__ffsll((long long)em) - 1u) slot0 = atomicAdd(&cont[0], (uint32_t)__popcll(em));
+                    slot0 = __shfl(slot0, __ffsll((long long)em) - 1, 64);
+                    const uint32_t slot = slot0 + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                    uint32_t ebase = 0;
+                    if (live && slot < tc.capHeaders) ebase = atomicAdd(&cont[kCursorStride], n);
+                    const bool fits = live && slot < tc.capHeaders && (uint64_t)ebase + n <= tc.capEntries;
+                    if (live && slot < tc.capHeaders) {  // a reserved header is always written: an empty one tells the drain to skip it
+                        tc.headers[2 * (size_t)slot] = make_uint4(fits ? rayIdx : kInvalid, __float_as_uint(best), __float_as_uint(hbu), __float_as_uint(hbv));
+                        tc.headers[2 * (size_t)slot + 1] = make_uint4(hitIdx, hitTri, ebase, fits ? n : 0u);
+                    }
+                    if (fits) {
+                        for (uint32_t k = 0; k < sp; ++k) tc.entries[ebase + k] = k < (uint32_t)kLdsStack ? sStack[k][tid] : myOverflow[k - kLdsStack];
+                        tc.entries[ebase + sp] = make_uint2(cur, 0u);  // (a leaf in progress is simply tested again from its first triangle)
+                        cur = kDone;
+                        rayIdx = kInvalid;  // the drain kernel writes this ray's hit record
+                        OKRT_HIST_DONE
+                    }
+                    if (__ballot(live && !fits)) tailOpen = false;  // pools full: finish here
+                }
+            }
+        }
+#endif
+
         // ---- one step per lane: a node visit OR a triangle test ("if-if" scheduling) ------------------------------
         // The first version descended in a while-while loop (all node steps, then all leaf triangles); with bounce
         // rays the lanes of a wave need very different numbers of steps before their next leaf and waited for the
@@ -176,7 +218,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         const bool isNode = cur != kDone && !(cur & kLeafBit);
         const bool isTri = cur != kDone && (cur & kLeafBit);
         const uint32_t wantNode = (uint32_t)__popcll(__ballot(isNode)), wantTri = (uint32_t)__popcll(__ballot(isTri));
-        bool runNode = wantNode >= sv.nodeMin, runTri = wantTri >= sv.triMin;
+        bool runNode = wantNode >= kNodeMin, runTri = wantTri >= kTriMin;
         if (!runNode && !runTri) {
             runNode = wantNode >= wantTri && wantNode;
             runTri = !runNode && wantTri;
@@ -269,7 +311,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                                                 mk(__uint_as_float(d2.x), __uint_as_float(d2.y), __uint_as_float(d2.z)), bu, bv);
             if (t > 0.f) {
                 const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314 with M = identity (world-space triangles)
-                if (d < best) {
+                if (closerHit(d, d0.w, d1.w, best, hitTri, hitIdx)) {
                     best = d;
                     hbu = bu;
                     hbv = bv;
@@ -285,6 +327,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         }
     }
 
+#if OKRT_TAIL_DRAIN
+    if (tv.ctr && lane == 0) atomicAdd(&tv.ctr[(xcc & (kShards - 1)) * kCursorStride], 1u);  // this wave is done
+#endif
 #ifdef OKRT_STAMPS
     for (int off = 32; off > 0; off >>= 1) {
         nodeWave += __shfl_down(nodeWave, off, 64); nodeLane += __shfl_down(nodeLane, off, 64);
@@ -509,7 +554,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                     const float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
                     if (t > 0.f) {
                         const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314
-                        if (d < best) {
+                        if (closerHit(d, __float_as_uint(t0.w), __float_as_uint(t1.w), best, hitTri, hitIdx)) {
                             best = d;
                             hbu = bu;
                             hbv = bv;
@@ -602,6 +647,138 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
     }
 }
 
+#if OKRT_TAIL_DRAIN
+// ---- tail drain -----------------------------------------------------------------------------------------------------
+// One wave per continuation (TailView): the exported stack goes into LDS and is traversed up to 64 entries at a time,
+// one entry per lane — a node visit pushes its entered children back (positions by ballot + prefix popcount), a leaf tests
+// its triangles — until the stack is empty. Every lane keeps the best candidate it has seen itself; the wave shares the
+// smallest distance for culling and the final winner is the candidate closerHit ranks first, so the result is the one
+// the sequential kernels compute. The number of entries taken per round shrinks as the stack fills, down to one (plain
+// depth-first, bounded by 3 * depth + 4), so kDrainStack entries always suffice (checked on the host).
+__global__ __launch_bounds__(64) void drainKernel(FastView fv, RayQueue q, HitBuffer hb, TailView tv, uint32_t maxDepth) {
+    __shared__ uint2 sh[kDrainStack];
+    const uint32_t lane = threadIdx.x;
+    const TailConst tc = *tv.tc;
+    uint32_t* cont = tv.ctr + kShards * kCursorStride;
+    // (everything that steers the loops is wave-uniform and kept in SGPRs by readfirstlane: no divergent control flow around them)
+    const uint32_t total = __builtin_amdgcn_readfirstlane(min(__hip_atomic_load(&cont[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tc.capHeaders));
+    const uint32_t roomLimit = kDrainStack - 3u * maxDepth - 8u;  // beyond this only one entry is taken per round
+    for (uint32_t guard = 0; guard <= tc.capHeaders; ++guard) {  // (at most one pass per header for a single wave)
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&cont[2 * kCursorStride], 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= total) break;
+        const uint4 h0 = tc.headers[2 * (size_t)c], h1 = tc.headers[2 * (size_t)c + 1];
+        const uint32_t rayIdx = __builtin_amdgcn_readfirstlane(h0.x), count = __builtin_amdgcn_readfirstlane(h1.w);
+        if (rayIdx == kInvalid || count == 0u) continue;
+        const float4 A = ldStream(&q.a[rayIdx]), B = ldStream(&q.b[rayIdx]);
+        const V3 ro = mk(A.x, A.y, A.z);
+        const V3 rdir = normalize(mk(A.w, B.x, B.y));
+        V3 iq = rcp3(rdir);
+        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
+        __syncthreads();  // (one wave per block: orders the previous continuation's reads of `sh` before these writes)
+        for (uint32_t k = lane; k < count && k < kDrainStack; k += 64) sh[k] = tc.entries[h1.z + k];
+        __syncthreads();
+        uint32_t sp = min(count, kDrainStack);                 // wave-uniform
+        float cull = __uint_as_float(h0.y);                    // smallest distance anybody has found: box culling
+        float best = lane == 0 ? cull : kFltMax;               // this lane's own candidate (lane 0 carries the exported one)
+        float hbu = __uint_as_float(h0.z), hbv = __uint_as_float(h0.w);
+        uint32_t hitIdx = lane == 0 ? h1.x : kInvalid, hitTri = lane == 0 ? h1.y : kInvalid;
+        uint32_t rounds = 0;
+        while (sp > 0 && ++rounds < 4096u) {  // (the bound is never reached on a valid tree: an exit every wave reaches whatever the tables hold)
+            sp = __builtin_amdgcn_readfirstlane(sp);
+            uint32_t take = min(sp, 64u);
+            if (sp + 3u * take > roomLimit) take = sp < roomLimit ? max((roomLimit - sp) / 3u, 1u) : 1u;
+            take = min(take, sp);
+            uint2 e = make_uint2(kDone, 0u);
+            if (lane < take) e = sh[sp - 1u - lane];
+            sp -= take;
+            __syncthreads();
+            const bool alive = lane < take && __uint_as_float(e.y) < cull;
+            const bool isNode = alive && !(e.x & kLeafBit);
+            float tn[4] = {kFltMax, kFltMax, kFltMax, kFltMax};
+            uint32_t ch[4] = {kDone, kDone, kDone, kDone};
+            if (isNode) {
+                const uint4* p = fv.nodes + (size_t)e.x * 4;
+                const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
+                ch[0] = n1.x; ch[1] = n1.y; ch[2] = n1.z; ch[3] = n1.w;
+                const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
+                const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
+                const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
+                const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
+                const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
+                const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
+                                              fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
+                    const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
+                                             fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
+                    const bool hit = tfar >= tnear && tfar > 0.f && tnear < cull && ch[k] != kEmptyRef;
+                    tn[k] = hit ? tnear : kFltMax;
+                }
+            } else if (alive) {  // a leaf: all of its triangles
+                const uint32_t first = e.x & 0x07FFFFFFu, cnt = ((e.x >> 27) & 15u) + 1u;
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint4* p = (const uint4*)fv.tris + (size_t)(first + j) * 3;
+                    const uint4 d0 = p[0], d1 = p[1], d2 = p[2];
+                    float bu = 0.f, bv = 0.f;
+                    const float t = rayAndTriangleEdges(ro, rdir, mk(__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)),
+                                                        mk(__uint_as_float(d1.x), __uint_as_float(d1.y), __uint_as_float(d1.z)),
+                                                        mk(__uint_as_float(d2.x), __uint_as_float(d2.y), __uint_as_float(d2.z)), bu, bv);
+                    if (t > 0.f) {
+                        const float d = length(rdir * t);
+                        if (closerHit(d, d0.w, d1.w, best, hitTri, hitIdx)) {
+                            best = d;
+                            hbu = bu;
+                            hbv = bv;
+                            hitTri = d0.w;
+                            hitIdx = d1.w;
+                        }
+                    }
+                }
+            }
+            // entered children go back on the shared stack: child slot k of every lane, slot after slot
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool push = tn[k] < kFltMax;
+                const unsigned long long m = __ballot(push);
+                if (push) {
+                    const uint32_t pos = sp + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < kDrainStack) sh[pos] = make_uint2(ch[k], __float_as_uint(tn[k]));
+                }
+                sp = min(sp + (uint32_t)__popcll(m), kDrainStack);
+            }
+            float m = best;  // share the smallest distance found so far
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+            cull = fminf(cull, m);
+            __syncthreads();
+        }
+        // the winner: smallest distance, then closerHit's order (sphere first, then smaller triangle, then smaller instance)
+        float m = best;
+        for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+        const bool cand = best == m && m < kFltMax;
+        const uint32_t kt = cand ? hitTri + 1u : 0xFFFFFFFFu;  // kInvalid (a sphere hit) wraps to 0: ranks first
+        uint32_t mt = kt;
+        for (int off = 32; off > 0; off >>= 1) mt = min(mt, (uint32_t)__shfl_xor((int)mt, off, 64));
+        const bool cand2 = cand && kt == mt;
+        const uint32_t ki = cand2 ? hitIdx : 0xFFFFFFFFu;
+        uint32_t mi = ki;
+        for (int off = 32; off > 0; off >>= 1) mi = min(mi, (uint32_t)__shfl_xor((int)mi, off, 64));
+        const unsigned long long win = __ballot(cand2 && ki == mi);
+        if (win == 0ull) {  // nothing was hit at all
+            if (lane == 0) {
+                stStream(&hb.h[rayIdx], make_float4(kFltMax, 0.f, 0.f, __uint_as_float(kInvalid)));
+                stStream(&hb.tri[rayIdx], kInvalid);
+            }
+        } else if (lane == (uint32_t)__ffsll((long long)win) - 1u) {
+            stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
+            stStream(&hb.tri[rayIdx], hitTri);
+        }
+    }
+}
+#endif  // OKRT_TAIL_DRAIN
+
 // Known-answer probe (okrt_debug_kat, CLOSEST_HIT_FAST): one thread per ray walks the structure with a private stack —
 // the same node decoding, slab arithmetic, triangle test and hit-distance formula as the trace kernels, none of their
 // scheduling — so tests can compare the structure's closest hit with the oracle's ray by ray.
@@ -642,7 +819,7 @@ __global__ __launch_bounds__(64) void fastKatKernel(const uint4* __restrict__ no
                 const float t = rayAndTriangleEdges(ro, rdir, mk(t0.x, t0.y, t0.z), mk(t1.x, t1.y, t1.z), mk(t2.x, t2.y, t2.z), bu, bv);
                 if (t > 0.f) {
                     const float d = length(rdir * t);
-                    if (d < best) {
+                    if (closerHit(d, __float_as_uint(t0.w), __float_as_uint(t1.w), best, hitTri, hitIdx)) {
                         best = d;
                         hitTri = __float_as_uint(t0.w);
                         hitIdx = __float_as_uint(t1.w);
@@ -679,10 +856,19 @@ __global__ __launch_bounds__(64) void fastKatKernel(const uint4* __restrict__ no
 }  // namespace
 
 void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
-                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals) {
+                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals,
+                 const TailView& tv) {
     const dim3 tb(kTraceThreads);
-    if (count) hipLaunchKernelGGL((traceKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
-    else hipLaunchKernelGGL((traceKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+    if (count) hipLaunchKernelGGL((traceKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, tv);
+    else hipLaunchKernelGGL((traceKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, tv);
+}
+
+void launchDrain(dim3 grid, hipStream_t stream, const FastView& fv, RayQueue q, HitBuffer hb, const TailView& tv, uint32_t maxDepth) {
+#if OKRT_TAIL_DRAIN
+    hipLaunchKernelGGL(drainKernel, grid, dim3(64), 0, stream, fv, q, hb, tv, maxDepth);
+#else
+    (void)grid; (void)stream; (void)fv; (void)q; (void)hb; (void)tv; (void)maxDepth;
+#endif
 }
 
 void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,

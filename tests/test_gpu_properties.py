@@ -372,3 +372,4 @@ def test_random_call_sequences_deferred_equals_immediate(seed):
             assert x.shape == y.shape and np.array_equal(x, y, equal_nan=(x.dtype.kind == "f"))
         else:
             assert x == y
+
