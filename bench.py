@@ -465,7 +465,7 @@ def main():
             ctx.synchronize()
             return (time.perf_counter() - t1) * 1e3 / 64
         single_sync_ms = per_call(0)   # every okrt_render launches its own frame
-        single_ms = per_call(32)       # the default: the library defers and batches the accumulation loop's frames
+        single_ms = per_call(16)       # the default: the library defers and batches the accumulation loop's frames
 
     rays_total, elapsed_max = rays_local, elapsed
     if world > 1:

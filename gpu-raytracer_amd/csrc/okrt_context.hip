@@ -53,7 +53,7 @@ struct okrt_ctx {
     uint32_t builder = 0;           // OKRT_OPT_BUILDER
     // Deferred okrt_render calls (OKRT_OPT_DEFER): consecutive frames of an unchanged scene wait here and are traced by
     // one launch set (renderImpl with frames > 1); anything that observes or changes state flushes them first.
-    uint32_t pending = 0, deferMax = 32;
+    uint32_t pending = 0, deferMax = 16;
     uint32_t batchLimit = kMaxFramesPerLaunch;  // halved when the queues of a launch set do not fit in memory
     okrt_render_data pendingRd{};
     bool externalFramebuffers = false, externalStream = false;

@@ -77,7 +77,7 @@ struct FastScene {
     DeviceBuilder* builder = nullptr;  // device-side build scratch (okrt_fast_build_device.hip), made on first use
     FastBuildInfo info = {};
     // pipeline state, sized lazily for the tile
-    size_t capacity = 0;
+    size_t capacity = 0, capacityQ0 = 0;  // items queue 1 + the hit records / queue 0 are allocated for
     RayQueue q[2] = {};
     HitBuffer hb = {};
     uint32_t* counts = nullptr;  // per segment b, shard s: count at (b*kShards + s)*kCursorStride, cursor at kCursorBase + the same
@@ -228,19 +228,38 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     const uint32_t total = perFrame * frames;
     const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
     const size_t items = (size_t)cap * kShards;
-    // per item: two ray queues (16+16+16+8 B each) + hit record (16+4 B); per pixel and frame: a 16-byte radiance slot
-    const size_t needBytes = items * (2 * 56 + 20) + (frames > 1 ? (size_t)t.rows * t.W * frames * 16 : 0);
+    // Queue 1 (56 B per item) and the hit records (20 B) are always needed. Queue 0 only exists when something uses it:
+    // the unfused camera segment (generate -> trace -> shade) or a third segment (queues ping-pong from b = 2 on); with
+    // the fused camera kernel and NUM_BOUNCES = 1 — the reference's configuration — it is never allocated: 76 instead of
+    // 132 bytes per ray and frame in flight. Per pixel and frame of a multi-frame set: a 16-byte radiance slot.
+    static const bool envPacket0 = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
+    static const bool envFused0 = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
+    const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2;
+    const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 ? (size_t)t.rows * t.W * frames * 16 : 0);
     if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
         err = "launch set exceeds the queue memory budget";
         return LaunchStatus::OutOfMemory;
     }
     if (items > fs.capacity) {
         hipStreamSynchronize(stream);
-        fs.capacity = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
-        for (RayQueue& q : fs.q)
-            if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return LaunchStatus::OutOfMemory;
+        fs.capacity = fs.capacityQ0 = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
+        for (RayQueue* q : {&fs.q[0], &fs.q[1]})
+            for (void** p : {(void**)&q->a, (void**)&q->b, (void**)&q->c, (void**)&q->d}) {
+                if (*p) hipFree(*p);
+                *p = nullptr;
+            }
+        RayQueue& q = fs.q[1];
+        if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return LaunchStatus::OutOfMemory;
         if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return LaunchStatus::OutOfMemory;
         fs.capacity = items;
+    }
+    if (needQ0 && items > fs.capacityQ0) {
+        hipStreamSynchronize(stream);
+        fs.capacityQ0 = 0;
+        RayQueue& q = fs.q[0];
+        if (!devAlloc(&q.a, fs.capacity, err) || !devAlloc(&q.b, fs.capacity, err) || !devAlloc(&q.c, fs.capacity, err) || !devAlloc(&q.d, fs.capacity, err))
+            return LaunchStatus::OutOfMemory;
+        fs.capacityQ0 = fs.capacity;
     }
     const size_t pixels = (size_t)t.rows * t.W;
     float4* radiance = nullptr;

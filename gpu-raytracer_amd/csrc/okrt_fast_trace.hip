@@ -286,6 +286,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                             sStack[sp][tid] = make_uint2(ch[k], __float_as_uint(tn[k]));
                         } else if (sp - kLdsStack < fv.overflowCap) {
                             myOverflow[sp - kLdsStack] = make_uint2(ch[k], __float_as_uint(tn[k]));
+#ifdef OKRT_ITER_HIST
+                            if (COUNT && counters) atomicAdd(&counters[11], 1ull);  // diagnostic: stack entries spilled to the HBM slab
+#endif
                         } else {
                             continue;  // cannot happen: the slab is sized from the tree depth
                         }

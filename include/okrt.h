@@ -138,16 +138,21 @@ typedef enum okrt_option {
      *     Application.cpp:312-317 on every scene edit, at interactive rates. Both cover exactly the triangles the
      *     reference shader reaches, so renders agree up to equal-distance ties. */
     OKRT_OPT_BUILDER = 4,
-    /* n >= 2 (default 32): okrt_render calls that continue the progressive accumulation of an unchanged scene (same
+    /* n >= 2 (default 16): okrt_render calls that continue the progressive accumulation of an unchanged scene (same
      * RenderData apart from numAccumulationFrames = previous + 1, fast traversal, no debug mode, library-owned stream
      * and framebuffers) are deferred and up to n of them traced by one set of kernel launches — the reference's
      * main loop `for (;;) render();` (Application.cpp:106-128) gets the throughput of okrt_render_frames without a
-     * change to the host. Every other entry point (read-backs, synchronize, uploads that change a table, options,
-     * timers, ...) executes the waiting frames first, so nothing can observe the deferral; the framebuffers are
-     * bit-identical to immediate execution. 0 or 1 = launch every frame inside its own okrt_render. */
+     * change to the host. Arguments and tables are validated inside the deferred call itself; what can only surface
+     * later (at the call that executes the frames) is a failing device allocation or launch. Every other entry point
+     * (read-backs, synchronize, uploads that change a table, options, timers, ...) executes the waiting frames first,
+     * so nothing can observe the deferral; the framebuffers are bit-identical to immediate execution. 0 or 1 = launch
+     * every frame inside its own okrt_render.
+     * Footprint: a launch set of F frames keeps (76 B per ray + 16 B per pixel) x F of queues in flight (132 B per ray
+     * when NUM_BOUNCES >= 2): 1920x1080 -> 0.19 GB per frame, 3.0 GB at the default of 16, 12 GB at the maximum of 64;
+     * 3840x2160 -> 0.76 GB per frame. OKRT_OPT_QUEUE_MEMORY_MB bounds it. */
     OKRT_OPT_DEFER = 5,
-    /* Upper bound, in MiB, for the ray queues of one launch set (132 bytes per ray and frame in flight + 16 per
-     * pixel and frame; 1080p x 64 frames = 18 GiB). 0 (default) = whatever hipMalloc grants. A launch set that
+    /* Upper bound, in MiB, for the ray queues of one launch set (76 or 132 bytes per ray and frame in flight + 16 per
+     * pixel and frame, see OKRT_OPT_DEFER; 1080p x 64 frames = 12 GiB). 0 (default) = whatever hipMalloc grants. A launch set that
      * does not fit — by this bound or by the allocator — is split in halves until it does; a single frame is
      * always attempted. */
     OKRT_OPT_QUEUE_MEMORY_MB = 6

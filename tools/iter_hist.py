@@ -14,5 +14,6 @@ for mb, what in ((0, "camera tiles (packet kernel): node steps + triangle tests 
     rt.ctx.set_option(abi.OPT_MAX_BOUNCES, mb)
     rt.resetAccumulation(); rt.render()
     rt.ctx.set_option(abi.OPT_COUNTERS, 1); rt.ctx.reset_counters(); rt.resetAccumulation(); rt.render(); c = rt.ctx.counters(); rt.ctx.set_option(abi.OPT_COUNTERS, 0)
-    print(f"{wl} max_bounces={mb}: {what}; max {c['fast_nodes']}")
+    print(f"{wl} max_bounces={mb}: {what}; max {c['fast_nodes']}; stack entries spilled to the HBM slab by the per-ray kernel: {c['fast_tris']} "
+          f"({c['fast_tris'] * 8 / 1e6:.1f} MB of 8-byte writes per frame)")
     print("   " + "  ".join(f"{n}: {c[k]}" for n, k in zip(names, keys)))
