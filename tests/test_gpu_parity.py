@@ -221,3 +221,43 @@ def test_resize_reallocates_and_resets(oracle):
     ort.render()
     assert_1spp(a, ort.ctx.read_accum())
     ort.close()
+
+
+def test_hip_path_against_the_independent_python_derivation():
+    """The product against the Python re-derivation of tests/test_oracle_paths.py DIRECTLY (no C++ oracle in between): the
+    textured, instanced, lit mesh scene with the brute-force closest hit, and the total-internal-reflection scene, both
+    traversals. The device libm differs from Python's float64 in the last float32 ulp of sin / cos / log, so a few pixels
+    may take another stochastic branch; the rest must agree to 2e-4."""
+    import math
+    import test_oracle_paths as P
+    desc = scenes.small_mesh_scene(seed=3, n_objects=4, detail=4, transforms=True, with_lights=True, octree=(0, 50), tex_size=8)
+    desc.env_cross = P.constant_face_cross(4)
+    W, H = 32, 18
+    rt, sc, res = scenes.instantiate(desc, W, H)
+    tri_pos = rt.table(0).view(np.float32).reshape(-1, 3, 3).astype(np.float64)
+    tri_info = rt.table(1).view(np.float32).reshape(-1, 3, 11).astype(np.float64)
+    tex = rt.table(3)
+    inst = []
+    for rec in rt.table(7):
+        f = rec[:128].view(np.float32).astype(np.float64)
+        u = rec[128:136].view(np.uint32)
+        inst.append(dict(M=f[:16].reshape(4, 4), Minv=f[16:32].reshape(4, 4), tri0=int(u[0]), tri1=int(u[1]), mat=P._material_from_record(rec[160:228])))
+    spheres = [dict(P.mat(**{k: v for k, v in m.items() if k in ("albedo", "roughness", "specular", "transparency")}, ior=m.get("indexOfRefraction", 1.0)),
+                    pos=np.array(p, float), radius=r) for (p, r, m) in desc.spheres]
+    lights = {"point": [(np.array(p, float), np.array(c, float), i, r) for (p, c, i, r) in desc.point_lights],
+              "spot": [(np.array(p, float), P.forward_vec(rot), np.array(c, float), i, r, math.cos(math.radians(a))) for (p, rot, c, i, r, a) in desc.spot_lights],
+              "dir": [(P.forward_vec(rot), np.array(c, float), i, math.cos(math.radians(a))) for (rot, c, i, a) in desc.dir_lights]}
+    for trav in (abi.TRAVERSAL_REFERENCE, abi.TRAVERSAL_FAST):
+        rt.ctx.set_option(abi.OPT_TRAVERSAL, trav)
+        rt.resetAccumulation()
+        rt.render()
+        rd = rt.render_data
+        want = np.zeros((H, W, 3))
+        for py in range(H):
+            for px in range(W):
+                want[py, px] = P.mesh_pixel(px, py, rd, spheres, inst, tri_pos, tri_info, tex, lights, 1)
+        got = rt.ctx.read_accum()
+        d = np.abs(got[..., :3].astype(np.float64) - want)
+        ok = d.max(-1) <= 2e-4 + 2e-4 * np.abs(want).max(-1)
+        assert ok.mean() >= 0.98, (trav, ok.mean(), float(d.max()))
+    rt.close()
