@@ -71,8 +71,7 @@ constexpr uint32_t kCursorStride = 32;  // words: one cursor per 128-byte line (
 // from `total`; queued rays: counts[] written by the shading kernel. cursors[] = next unreserved.
 struct ShardView {
     uint32_t cap, total;
-    uint32_t batch, xcdAffinity, refillBelow;  // tunables (developer knobs: OKRT_FAST_BATCH / _AFFINITY / _REFILL)
-    uint32_t nodeMin, triMin;                  // a step block runs when at least this many lanes want it (OKRT_FAST_NODE_MIN / _TRI_MIN)
+    uint32_t batch, xcdAffinity;  // tunables (developer knobs: OKRT_FAST_BATCH / _AFFINITY)
     const uint32_t* counts;  // counts[s * kCursorStride]; nullptr for camera rays
     uint32_t* cursors;       // cursors[s * kCursorStride]
     __device__ uint32_t count(uint32_t s) const {

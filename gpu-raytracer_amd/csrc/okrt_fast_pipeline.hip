@@ -290,11 +290,10 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     };
     static const uint32_t envBatch = getenv("OKRT_FAST_BATCH") ? (uint32_t)atoi(getenv("OKRT_FAST_BATCH")) : kBatch;
     static const uint32_t envAffinity = getenv("OKRT_FAST_AFFINITY") ? (uint32_t)atoi(getenv("OKRT_FAST_AFFINITY")) : 1u;
-    // (the refill threshold and the two step-block thresholds are compile-time constants of the trace kernel now:
-    // -DOKRT_REFILL_BELOW / -DOKRT_NODE_MIN / -DOKRT_TRI_MIN with tools/build_variant.sh; three fewer SGPRs live in its loop)
-    const uint32_t envNodeMin = kNodeMin, envTriMin = kTriMin, envRefill = (uint32_t)kRefillBelow;
+    // (the refill threshold and the two step-block thresholds are compile-time constants of the trace kernel:
+    // -DOKRT_REFILL_BELOW / -DOKRT_NODE_MIN / -DOKRT_TRI_MIN with tools/build_variant_all.sh; three fewer SGPRs live in its loop)
     auto shards = [&](uint32_t b, bool camera) {
-        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, envRefill, envNodeMin, envTriMin, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
+        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
                          fs.counts + kCursorBase + b * kShards * kCursorStride};
     };
     // tail drain: on when the drain kernel's shared stack is certain to hold a traversal of this tree (depth-first bound
