@@ -65,7 +65,7 @@ constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorS
 // tail-drain counters of segment b (TailView): kShards exit counters, then continuation count / entry cursor / drain cursor
 constexpr uint32_t kTailStride = (kShards + 8) * kCursorStride;
 constexpr uint32_t kTailBase = kCountWords;
-constexpr uint32_t kAllCountWords = kTailBase + kMaxSegments * kTailStride;
+constexpr uint32_t kAllCountWords = kTailBase + (OKRT_TAIL_DRAIN ? kMaxSegments * kTailStride : 0u);  // (the experiment's counters only exist in its build)
 constexpr uint32_t kContinuations = 1u << 17;       // continuation headers per segment launch (32 B each)
 constexpr uint32_t kContinuationEntries = 1u << 22; // stack entries in the pool (8 B each)
 
