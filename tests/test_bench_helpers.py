@@ -1,0 +1,72 @@
+"""bench.py's bookkeeping that decides whether a committed PMC measurement may be attached to a bench line
+(roofline.traffic), and the roofline object's invariants — on CPU, with synthetic inputs."""
+import json
+import os
+import sys
+import types
+
+import pytest
+
+from conftest import REPO
+
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def test_kernel_source_fingerprint_is_stable_and_sensitive(tmp_path, monkeypatch):
+    a = bench.kernel_source_sha()
+    assert a == bench.kernel_source_sha() and len(a) == 16
+    # a different tree (an extra device source) gives a different fingerprint
+    fake = tmp_path / "gpu-raytracer_amd" / "csrc"
+    fake.mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    (fake / "k.hip").write_text("__global__ void k() {}\n")
+    (tmp_path / "include" / "okrt.h").write_text("/* */\n")
+    (tmp_path / "gpu-raytracer_amd" / "build.py").write_text("\n")
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    b = bench.kernel_source_sha()
+    (fake / "k.hip").write_text("__global__ void k() { }\n")
+    assert b != a and bench.kernel_source_sha() != b
+
+
+def test_stale_or_mismatched_pmc_files_are_not_attached(tmp_path, monkeypatch):
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "feedfacefeedface")
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    got, why = bench.load_pmc("sponza", 20)
+    assert got is None and "no profiles" in why
+    good = {"workload": "sponza", "frames_per_launch": 20, "source_sha": "feedfacefeedface", "kernels": {"traceKernel": {"hbm_bytes_per_launch": 1.0}}}
+    json.dump(dict(good, source_sha="0000000000000000"), open(tmp_path / "profiles" / "r01_pmc_sponza_f20.json", "w"))
+    got, why = bench.load_pmc("sponza", 20)
+    assert got is None and "other kernel sources" in why            # measured before the kernels changed
+    json.dump(dict(good, frames_per_launch=64), open(tmp_path / "profiles" / "r02_pmc_sponza_f64.json", "w"))
+    got, why = bench.load_pmc("sponza", 20)
+    assert got is None and "launch sets of 64" in why                # right kernels, other launch-set size
+    json.dump(good, open(tmp_path / "profiles" / "r03_pmc_sponza_f20.json", "w"))
+    got, why = bench.load_pmc("sponza", 20)
+    assert why is None and got[0] == "r03_pmc_sponza_f20.json" and got[1]["kernels"]["traceKernel"]["hbm_bytes_per_launch"] == 1.0
+    assert bench.load_pmc("dragon", 20)[0] is None                   # another workload's file is never used
+
+
+def test_roofline_report_is_a_fraction_and_names_its_basis(monkeypatch):
+    monkeypatch.setattr(bench, "load_pmc", lambda w, f: (None, "test"))
+    args = types.SimpleNamespace(traversal="fast", max_bounces=1, workload="sponza")
+    px, rays = 2_073_600, 4_099_000
+    # one Sponza-class 1080p frame: 32 400 camera tiles x (18.9 node steps + 7.7 triangle tests) x 64 lanes, 2.03 M bounce
+    # rays x (15.85 + 4.45) lane-level steps
+    fast = dict(pixels=px, segments=rays, fast_nodes=39_100_000 + 32_200_000, fast_tris=16_000_000 + 9_000_000, mesh_hits=4_000_000, tex_taps=4_100_000, env_taps=90_000)
+    cam = dict(fast, segments=px, fast_nodes=39_100_000, fast_tris=16_000_000, mesh_hits=2_030_000, tex_taps=2_080_000, env_taps=43_000)
+    ref = dict(segments=rays)
+    build = dict(num_nodes=65_500, num_triangles=262_267)
+    rep = bench.roofline_report(args, 1, False, [12.7, 0.01, 17.5, 6.1], 1, 64, build, ref, fast, cam, 117.9e9, 1e9, 0.47, 0.095, 0.0)
+    assert rep["kernel"].startswith("traceKernel") and rep["frames_per_launch"] == 64 and rep["traffic"] is None and rep["traffic_stale"]
+    assert 0 < rep["frac"] <= 1 and "algorithmic" in rep["frac_basis"]
+    for k in rep["kernels"]:
+        assert 0 < k["algorithmic_frac"] <= 1 and 0 < k["l2_frac"] <= 1, k
+    assert rep["reference_work_ratio"] > 1  # the reference's traversal order would touch far more bytes than HBM could deliver
+    # with a matching measurement the fraction is the measured one
+    pmc = {"kernels": {"traceKernel": {"hbm_bytes_per_launch": 17.1e9, "l2_hit_pct": 84.5, "valu_lane_util": 0.565}}}
+    monkeypatch.setattr(bench, "load_pmc", lambda w, f: (("r99_pmc_sponza_f64.json", pmc), None))
+    rep = bench.roofline_report(args, 1, False, [12.7, 0.01, 17.5, 6.1], 1, 64, build, ref, fast, cam, 117.9e9, 1e9, 0.47, 0.095, 0.0)
+    assert rep["traffic"] == int(17.1e9) and not rep["traffic_stale"] and "measured" in rep["frac_basis"]
+    assert abs(rep["frac"] - 17.1e9 / 17.5e-3 / 8e12) < 1e-3 and rep["valu_lane_util"] == 0.565
