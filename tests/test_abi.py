@@ -24,12 +24,29 @@ def test_libokrt_exports_every_declared_entry_point():
     assert lib.okrt_abi_version() == abi.OKRT_ABI_VERSION
 
 
-def test_api_table_is_complete():
+def api_table_entries():
+    text = open(os.path.join(REPO, "include", "okrt.h")).read()
+    body = text[text.index("typedef struct okrt_api {"):text.index("} okrt_api;")]
+    return re.findall(r"\(\*([a-z0-9_]+)\)\(", body)
+
+
+def test_api_table_is_complete(oracle):
+    """ABI 2: the okrt_api table carries the WHOLE surface; the product fills every entry, and every declared okrt_*
+    entry point (bar create-time helpers that cannot go through a table) has one."""
+    names = api_table_entries()
+    assert len(names) == 41 and len(set(names)) == len(names)
     lib = C.CDLL(abi.device_library_path())
-    lib.okrt_get_api.restype = C.POINTER(C.c_void_p * 20)
+    lib.okrt_get_api.restype = C.POINTER(C.c_void_p * (len(names) + 1))
     table = lib.okrt_get_api().contents
     assert C.cast(C.pointer(table), C.POINTER(C.c_uint32)).contents.value == abi.OKRT_ABI_VERSION
-    assert all(table[i] for i in range(1, 20))  # 19 function pointers, none NULL
+    assert all(table[i] for i in range(1, len(names) + 1))  # no NULL in the product's table
+    declared = {s[len("okrt_"):] for s in header_symbols()} - {"abi_version", "get_api"}
+    assert declared <= set(names), sorted(declared - set(names))
+    # the CPU checker implements the first 19 (the scene-upload / render / read-back core) and leaves the rest NULL
+    oracle.lib.okrt_oracle_get_api.restype = C.POINTER(C.c_void_p * (len(names) + 1))
+    otable = oracle.lib.okrt_oracle_get_api().contents
+    assert all(otable[i] for i in range(1, 20)) and not any(otable[i] for i in range(20, len(names) + 1))
+    oracle.lib.okrt_oracle_get_api.restype = C.c_void_p
 
 
 def test_layout_constants():
