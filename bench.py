@@ -5,11 +5,18 @@
 
 A "step" is one frame = one sample per pixel of the whole frame. N = 1: the workload is
 BASELINE.json's headline config (Sponza-class 1920x1080, configs[3]; procedural stand-in of
-262 267 triangles / 390 meshes / 26 textures). N > 1 (launched by
-torch.distributed.run): the SAME frame is split into interleaved 8-row stripes, rank r owns stripes
-r, r+N, ...; scene tables are replicated; there is no data-path collective per frame — the per-rank
-float4 accumulation tiles are gathered to rank 0 over RCCL every 64 frames and after the last one
-(inside the timed region). Total work is fixed, so "scaling" is "strong".
+262 267 triangles / 390 meshes / 26 textures). N > 1: the SAME frame is split into
+interleaved 8-row stripes, rank r owns stripes r, r+N, ...; scene tables are replicated; there is no
+data-path collective per frame — the per-rank float4 accumulation tiles are gathered to rank 0 over
+RCCL (okrt_mgpu_gather_accum[_all], behind the C ABI) every 64 frames and after the last one, inside
+the timed region. Total work is fixed, so "scaling" is "strong".
+
+N > 1 starts either way (gpu-raytracer_amd/mgpu.py: launch_plan), without torch:
+  python bench.py --gpus N                                   one process drives N contexts (ncclCommInitAll, one group)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+                                                             one process per rank (RANK / WORLD_SIZE from the launcher);
+                                                             the RCCL id travels through a file store
+With fewer GPUs than ranks either form runs as a clearly marked REHEARSAL (ranks share GPUs).
 
 The JSON line carries the roofline of the dominant kernel family (BVH traversal) and a CPU baseline
 (the scalar oracle on this box's host cores, bounded sample, rank 0, N = 1 only).
@@ -81,23 +88,6 @@ def load_pmc(workload, frames_per_launch):
             continue
         best = (os.path.basename(f), j)
     return (best, None) if best else (None, why)
-
-
-def assert_single_hip_runtime():
-    """N > 1 shares device pointers and a stream between torch (RCCL collectives) and libokrt.so (kernels): both must
-    be bound to ONE libamdhip64 instance. Two mapped copies (libokrt.so loaded before torch, or an LD_LIBRARY_PATH that
-    resolves the soname differently) would each open the GPU on their own and the first cross-library pointer would
-    fault — fail here, with the paths, instead."""
-    paths = set()
-    try:
-        for line in open("/proc/self/maps"):
-            if "libamdhip64" in line:
-                paths.add(os.path.realpath(line.split()[-1]))
-    except OSError:
-        return
-    if len(paths) > 1:
-        raise SystemExit("bench.py: two HIP runtimes are mapped into this process (" + ", ".join(sorted(paths)) + "): import torch BEFORE "
-                         "loading libokrt.so, and do not point LD_LIBRARY_PATH at another ROCm; N > 1 needs one runtime instance")
 
 
 def usable_cpus():
@@ -274,6 +264,14 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
     }
 
 
+class RankState:
+    """One rank this process drives: its RayTracer (host layer) on its device, with the rank's tile."""
+
+    def __init__(self, rank, device, rt, scene, res):
+        self.rank, self.device, self.rt, self.scene, self.res = rank, device, rt, scene, res
+        self.ctx = rt.ctx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,7 +279,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single-call", action="store_true", help="skip the one-okrt_render-per-frame timing (profiling runs: every launch set then has frames_per_launch frames)")
+    ap.add_argument("--no-single-call", action="store_true", help="skip the one-okrt_render-per-frame and 1024-spp timings (profiling runs: every launch set then has frames_per_launch frames)")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
     ap.add_argument("--max-bounces", type=int, default=1, help="NUM_BOUNCES (RaytracerCS.hlsl:6; HEAD = 1, used for every graded number)")
     ap.add_argument("--split", default="tiles", choices=["tiles", "samples"],
@@ -291,122 +289,84 @@ def main():
                     help="consecutive frames traced by one set of kernel launches (okrt_render_frames); 0 = auto")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-        args.gpus = world
-
-    if world > 1:
-        # torch bundles its own HIP runtime (same soname as /opt/rocm's). It must be loaded BEFORE libokrt.so so that
-        # both share ONE runtime instance (device pointers and streams cross the boundary); two runtimes in a process
-        # cannot both open the GPU.
-        import torch  # noqa: F401
     abi = importlib.import_module("gpu-raytracer_amd._abi")
     scenes = importlib.import_module("gpu-raytracer_amd.scenes")
+    mgpu = importlib.import_module("gpu-raytracer_amd.mgpu")
+    # who drives which rank: decided from the command line and the environment BEFORE anything touches a GPU
+    #   plain `python bench.py --gpus N`       -> this one process drives N contexts (C-ABI exchange, no launcher needed)
+    #   under a launcher (WORLD_SIZE / RANK)   -> one process per rank; the launcher's world size wins over --gpus
+    plan = mgpu.launch_plan(args.gpus, os.environ, None)
     fns = abi.load_device_library()  # raises if libokrt.so is missing: no fallback
-    if world > 1:
-        assert_single_hip_runtime()
+    plan = mgpu.launch_plan(args.gpus, os.environ, mgpu.visible_gpus(fns))
+    world, rank = plan["world"], plan["rank"]
+    args.gpus = world
+    store = mgpu.FileStore(rank, world) if plan["mode"] == "process_per_gpu" else None
 
     builder, kwargs, W, H, wl_desc = WORKLOADS[args.workload]
     desc = getattr(scenes, builder)(**kwargs)
 
-    dist = torch = None
-    backend, device_index = "none", local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        ndev = torch.cuda.device_count()
-        if ndev >= world:
-            backend = "nccl"  # RCCL: one GPU per rank, tiles move GPU -> GPU over xGMI
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            # rehearsal only (fewer GPUs than ranks, e.g. 2 ranks on a 1-GPU box): ranks share a GPU and the tiles
-            # are gathered through host memory with gloo; everything but the RCCL transport is exercised
-            backend = "gloo"
-            device_index = local_rank % max(ndev, 1)
-            torch.cuda.set_device(device_index)
-            dist.init_process_group("gloo")
-
-    rt, scene, res = scenes.instantiate(desc, W, H, device=device_index)
-    ctx = rt.ctx
-    ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
-    ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
-
+    # scene tables are replicated: every rank's context gets the same uploads through the host layer
+    def make_rank(r_dev):
+        r, dev = r_dev
+        rt, scene, res = scenes.instantiate(desc, W, H, device=dev)
+        return RankState(r, dev, rt, scene, res)
+    importlib.import_module("gpu-raytracer_amd.host").host_library()  # loaded once, before any worker thread needs it
+    if len(plan["local_ranks"]) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(plan["local_ranks"]), usable_cpus())) as pool:
+            ranks = list(pool.map(make_rank, zip(plan["local_ranks"], plan["devices"])))
+    else:
+        ranks = [make_rank((plan["local_ranks"][0], plan["devices"][0]))]
+    rt, ctx = ranks[0].rt, ranks[0].ctx  # the rank whose kernels the roofline reports (rank 0 in one_process / single mode)
+    samples_split = world > 1 and args.split == "samples"
+    for st in ranks:
+        st.ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
+        st.ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
+        if world > 1 and not samples_split:
+            st.ctx.set_tile(STRIPE_ROWS, st.rank, world)
     if world == 1 and os.environ.get("OKRT_BENCH_TILE"):  # developer knob: time one rank's share of an N-way split on 1 GPU
         sr, si, ss = (int(v) for v in os.environ["OKRT_BENCH_TILE"].split(","))
         ctx.set_tile(sr, si, ss)
-    accum_t = gathered = None
-    samples_split = world > 1 and args.split == "samples"
-    if world > 1:
-        if samples_split:
-            max_rows = H  # whole frame on every rank
-        else:
-            ctx.set_tile(STRIPE_ROWS, rank, world)
-            max_rows = 0
-            for r in range(world):  # every rank pads its tile to the largest one so gather sizes match
-                n = sum(min(STRIPE_ROWS, H - s * STRIPE_ROWS) for s in range(r, (H + STRIPE_ROWS - 1) // STRIPE_ROWS, world))
-                max_rows = max(max_rows, n)
-        # the framebuffer lives in a torch tensor so RCCL can move it; okrt renders straight into it, on torch's stream
-        accum_t = torch.zeros((max_rows, W, 4), dtype=torch.float32, device=f"cuda:{device_index}")
-        result_t = torch.zeros((max_rows, W), dtype=torch.int32, device=f"cuda:{device_index}")
-        # one explicit (non-null) stream for both the kernels and the collective: stream order replaces host syncs
-        work_stream = torch.cuda.Stream(device=device_index)
-        torch.cuda.set_stream(work_stream)
-        ctx.set_stream(work_stream.cuda_stream)
-        ctx.bind_framebuffers(accum_t.data_ptr(), result_t.data_ptr())
-        if rank == 0:
-            gathered = [torch.empty_like(accum_t if backend == "nccl" else accum_t.cpu()) for _ in range(world)]
+    group = mgpu.TileGroup(fns, plan, [st.ctx.h for st in ranks], store, frame=(W, H, STRIPE_ROWS), read_tile=lambda k: ranks[k].ctx.read_accum())
 
-    def gather_tiles(final=False):
+    def exchange(final=False):
         if world <= 1:
             return
         if samples_split:  # disjoint frame indices, same pixels: one sum at the very end
             if final:
-                if backend == "nccl":
-                    dist.reduce(accum_t, dst=0, op=dist.ReduceOp.SUM)
-                else:
-                    host_acc = accum_t.cpu()
-                    dist.reduce(host_acc, dst=0, op=dist.ReduceOp.SUM)
-                    if rank == 0:
-                        gathered[0].copy_(host_acc)
+                group.reduce()
             return
-        src = accum_t if backend == "nccl" else accum_t.cpu()
-        dist.gather(src, gathered if rank == 0 else None, dst=0)
+        group.gather()
 
     def sync():
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-        ctx.synchronize()
+        for st in ranks:
+            st.ctx.synchronize()
+        if store:
+            store.barrier()
 
     # ---- roofline numerator: the reference-order counters of one frame of this workload -------
-    ref_counters = None
-    if rank == 0 or world > 1:
-        ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_REFERENCE)
-        ctx.set_option(abi.OPT_COUNTERS, 1)
-        ctx.reset_counters()
-        rt.render()
-        ref_counters = ctx.counters()
-        ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST)
-        rt.resetAccumulation()
-        ctx.reset_counters()
-        rt.render()  # same frame index through the fast pipeline: its own node / triangle visit counts
-        fast_counters = ctx.counters()
-        # the camera segment alone (max_bounces = 0): splits the node / triangle visit counts between the two traversal kernels
-        ctx.set_option(abi.OPT_MAX_BOUNCES, 0)
-        rt.resetAccumulation()
-        ctx.reset_counters()
-        rt.render()
-        camera_counters = ctx.counters()
-        ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
-        ctx.set_option(abi.OPT_COUNTERS, 0)
-        ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
-        rt.resetAccumulation()
+    def counted(st, traversal, max_bounces):
+        st.ctx.set_option(abi.OPT_TRAVERSAL, traversal)
+        st.ctx.set_option(abi.OPT_MAX_BOUNCES, max_bounces)
+        st.rt.resetAccumulation()
+        st.ctx.reset_counters()
+        st.rt.render()
+        return st.ctx.counters()
+
+    def add_counters(dicts):
+        return {k: sum(d[k] for d in dicts) for k in dicts[0]}
+
+    for st in ranks:
+        st.ctx.set_option(abi.OPT_COUNTERS, 1)
+    ref_counters = add_counters([counted(st, abi.TRAVERSAL_REFERENCE, args.max_bounces) for st in ranks])
+    fast_counters = add_counters([counted(st, abi.TRAVERSAL_FAST, args.max_bounces) for st in ranks])  # same frame index: its own node / triangle visit counts
+    # the camera segment alone (max_bounces = 0): splits the node / triangle visit counts between the two traversal kernels
+    camera_counters = add_counters([counted(st, abi.TRAVERSAL_FAST, 0) for st in ranks])
+    for st in ranks:
+        st.ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
+        st.ctx.set_option(abi.OPT_COUNTERS, 0)
+        st.ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
+        st.rt.resetAccumulation()
 
     # ---- warm-up, then exactly K timed steps ----------------------------------------------------
     # A step is one frame. Frames are handed to the device layer F at a time (okrt_render_frames): same framebuffers
@@ -416,45 +376,75 @@ def main():
     fpl = args.frames_per_launch or int(os.environ.get("OKRT_BENCH_FPL", "0")) or 64
     gather_every = int(os.environ.get("OKRT_BENCH_GATHER_EVERY", GATHER_EVERY))
     fpl = max(1, min(fpl, 64, gather_every))
+    enqueue_s = [0.0, 0]  # host time spent inside renderFrames calls (they must only ENQUEUE: that is what lets one thread feed N GPUs)
 
     def run_frames(n, gather):
         done = 0
         while done < n:
             m = min(fpl, n - done, gather_every - done % gather_every)
-            rt.renderFrames(m)
+            for st in ranks:  # asynchronous launches: the GPUs of a one-process job run concurrently
+                t_enq = time.perf_counter()
+                st.rt.renderFrames(m)
+                enqueue_s[0] += time.perf_counter() - t_enq
+                enqueue_s[1] += 1
             done += m
             if gather and done % gather_every == 0 and done != n:
-                gather_tiles()
+                exchange()
 
     run_frames(args.warmup, False)
     # also run one full-size launch set untimed unless the warm-up already did: its queues (GBs) are allocated on first use
     extra_warm = fpl if (args.warmup == 0 or args.warmup % fpl) else 0
     run_frames(extra_warm, False)
+    if world > 1 and not samples_split:
+        exchange()  # untimed: communicator warm-up (RCCL connects its channels on first use), staging buffers allocated
     steps_here = args.steps
     if samples_split:  # rank r renders frame indices r*K/N + 1 ... (r+1)*K/N of a fresh accumulation
         assert args.steps % world == 0, "--split samples needs steps divisible by the number of ranks"
         steps_here = args.steps // world
-        rt.resetAccumulation()
-        rt.render_data.numAccumulationFrames = rank * steps_here
+        for st in ranks:
+            st.rt.resetAccumulation()
+            st.rt.render_data.numAccumulationFrames = st.rank * steps_here
     sync()
-    ctx.reset_counters()
+    for st in ranks:
+        st.ctx.reset_counters()
     ctx.set_option(abi.OPT_TIMING, min(args.steps, 4096))  # HIP events around every kernel of every launch set, on the stream they run on
+    enqueue_s[0], enqueue_s[1] = 0.0, 0
+    sync()
     t0 = time.perf_counter()
     ctx.timer_begin()
     run_frames(steps_here, not samples_split)
     ctx.timer_end()
-    gather_tiles(final=True)
+    exchange(final=True)
     sync()
     elapsed = time.perf_counter() - t0
+    enqueue_ms_per_set = enqueue_s[0] * 1e3 / max(enqueue_s[1], 1)
     trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
     interval_ms, interval_launches, interval_frames = ctx.interval_ms()  # per kernel, launch sets of the size of the last one
     build = ctx.build_info()
     ctx.set_option(abi.OPT_TIMING, 0)
-    rays_local = ctx.counters()["segments"]
+    rays_local = sum(st.ctx.counters()["segments"] for st in ranks)
     if args.traversal == "reference":  # the reference-order kernel only counts with OKRT_OPT_COUNTERS (slow): segments of the counted frame x frames
         rays_local = ref_counters["segments"] * steps_here
-    # for reference: the same frames issued one okrt_render call per frame (the reference's main-loop shape)
-    single_ms = single_sync_ms = None
+    gpu_event_ms = ctx.timer_elapsed_ms()
+
+    # the combined frame on rank 0: every pixel must have received every frame
+    frames_done = args.steps if samples_split else args.warmup + extra_warm + args.steps
+    if world > 1:
+        full = group.read_full()
+        if full is not None:
+            assert bool((full[..., 3] == frames_done).all()), "combined frame: accumulation alpha != number of frames"
+    # one exchange on its own (all ranks idle before it starts): what a gather costs when nothing hides it
+    exchange_ms = None
+    if world > 1:
+        sync()
+        t1 = time.perf_counter()
+        exchange(final=True)
+        sync()
+        exchange_ms = (time.perf_counter() - t1) * 1e3
+
+    # for reference: the same frames issued one okrt_render call per frame (the reference's main-loop shape), and the
+    # configuration BASELINE.json names as such: 1024 spp of progressive accumulation, end to end
+    single_ms = single_sync_ms = spp1024_ms = readback_ms = None
     if world == 1 and not args.no_single_call:
         def per_call(defer):
             ctx.set_option(abi.OPT_DEFER, defer)
@@ -466,38 +456,36 @@ def main():
             return (time.perf_counter() - t1) * 1e3 / 64
         single_sync_ms = per_call(0)   # every okrt_render launches its own frame
         single_ms = per_call(16)       # the default: the library defers and batches the accumulation loop's frames
+        rt.resetAccumulation()
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        done = 0
+        while done < 1024:
+            rt.renderFrames(min(fpl, 1024 - done))
+            done += min(fpl, 1024 - done)
+        ctx.synchronize()
+        spp1024_ms = (time.perf_counter() - t1) * 1e3 / 1024
+        t1 = time.perf_counter()
+        img = ctx.read_result()  # the resolve is part of every launch set; this is the copy of the RGBA8 result to the host
+        readback_ms = (time.perf_counter() - t1) * 1e3
+        assert img.shape == (H, W, 4)
 
-    rays_total, elapsed_max = rays_local, elapsed
-    if world > 1:
-        red_dev = f"cuda:{device_index}" if backend == "nccl" else "cpu"
-        t = torch.tensor([float(rays_local), 0.0], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        rays_total = int(t[0].item())
-        tm = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        elapsed_max = float(tm.item())
-        ref_t = torch.tensor([float(ref_counters[k]) for k in sorted(ref_counters)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(ref_t, op=dist.ReduceOp.SUM)
-        ref_counters = {k: int(v) for k, v in zip(sorted(ref_counters), ref_t.tolist())}
-        fast_t = torch.tensor([float(fast_counters[k]) for k in sorted(fast_counters)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(fast_t, op=dist.ReduceOp.SUM)
-        fast_counters = {k: int(v) for k, v in zip(sorted(fast_counters), fast_t.tolist())}
-        cam_t = torch.tensor([float(camera_counters[k]) for k in sorted(camera_counters)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(cam_t, op=dist.ReduceOp.SUM)
-        camera_counters = {k: int(v) for k, v in zip(sorted(camera_counters), cam_t.tolist())}
-        st = torch.tensor([trace_ms, shade_ms, other_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(st, op=dist.ReduceOp.MAX)
-        trace_ms, shade_ms, other_ms = st.tolist()
+    # ---- job-wide sums and maxima (one_process: all ranks are local) -----------------------------
+    def job_sum(v):
+        return mgpu.allreduce_json(store, v, lambda xs: sum(xs))
 
-    if rank == 0 and world > 1:
-        if samples_split:
-            full = accum_t if backend == "nccl" else gathered[0]
-            frames_done = args.steps
-        else:
-            tiling = importlib.import_module("gpu-raytracer_amd.tiling")
-            full = tiling.deinterleave(gathered, H, STRIPE_ROWS)
-            frames_done = args.warmup + extra_warm + args.steps
-        assert bool((full[..., 3] == frames_done).all()), "combined frame: accumulation alpha != number of frames"
+    def job_max(v):
+        return mgpu.allreduce_json(store, v, lambda xs: max(xs))
+
+    def job_sum_dict(d):
+        return mgpu.allreduce_json(store, d, lambda ds: {k: sum(x[k] for x in ds) for k in ds[0]})
+    rays_total = job_sum(rays_local)
+    elapsed_max = job_max(elapsed)
+    if store:
+        ref_counters, fast_counters, camera_counters = job_sum_dict(ref_counters), job_sum_dict(fast_counters), job_sum_dict(camera_counters)
+        trace_ms, shade_ms, other_ms = job_max(trace_ms), job_max(shade_ms), job_max(other_ms)
+        exchange_ms = job_max(exchange_ms)
+
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
         mrays = rays_total / elapsed_max / 1e6
@@ -505,16 +493,40 @@ def main():
         frames = max(timed_frames, 1)
         trace_ms_frame = trace_ms / frames
         fpl_used = max(1, min(fpl, steps_here))  # the launch-set size the timed region really used
+        tile = {"rows": H, "bytes": H * W * 16}
+        if world > 1 and not samples_split:
+            tile = {"rows": ranks[0].ctx.tile_rows(), "bytes": ranks[0].ctx.tile_rows() * W * 16}
+        if world == 1:
+            gather_desc = "none"
+        elif samples_split:
+            gather_desc = f"one sum of the whole-frame float4 accumulations onto rank 0 after the last frame ({group.transport})"
+        else:
+            how = {"rccl": "RCCL point-to-point (one ncclSend per peer, one ncclRecv per peer on rank 0, one group) over xGMI",
+                   "copy": "REHEARSAL copy transport (ranks share a GPU: device copies instead of RCCL)"}.get(group.transport, group.transport)
+            gather_desc = f"{how}: packed float4 tiles to rank 0 every {gather_every} frames + final, de-interleaved there by one kernel"
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "traversal": args.traversal, "max_bounces": args.max_bounces, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl_used, "gpu_event_ms_per_step": round(ctx.timer_elapsed_ms() / max(steps_here, 1), 4), "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None, "ms_per_step_one_call_per_frame_defer_off": round(single_sync_ms, 4) if single_sync_ms else None,
+            "config": {"workload": wl_desc, "traversal": args.traversal, "max_bounces": args.max_bounces, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl_used,
+                       "gpu_event_ms_per_step": round(gpu_event_ms / max(steps_here, 1), 4),
+                       "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
+                       "ms_per_step_one_call_per_frame_defer_off": round(single_sync_ms, 4) if single_sync_ms else None,
+                       "ms_per_step_1024spp": round(spp1024_ms, 4) if spp1024_ms else None,
+                       "read_result_rgba8_ms": round(readback_ms, 3) if readback_ms else None,
+                       "launch": {"single": "one process, one context", "one_process": f"one process drives {world} contexts through the C ABI (no launcher, no torch)",
+                                  "process_per_gpu": f"one process per rank ({world}), RCCL id handed over through a file store (no torch)"}[plan["mode"]],
+                       "rehearsal": bool(plan["rehearsal"]), "devices": plan["devices"] if plan["mode"] != "process_per_gpu" else None,
                        "tile_split": ("samples split: every rank renders the whole frame for its own block of frame indices" if samples_split else
                                       f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks") if world > 1 else "full frame",
-                       "gather": (f"{'RCCL' if backend == 'nccl' else 'gloo (REHEARSAL: ranks share a GPU)'} gather of float4 tiles to rank 0 "
-                                  f"every {GATHER_EVERY} frames + final") if world > 1 else "none"},
+                       "gather": gather_desc, "gather_transport": group.transport if world > 1 else None,
+                       "gather_ms": round(exchange_ms, 3) if exchange_ms is not None else None,
+                       "gather_bytes_per_peer": tile["bytes"] if world > 1 else None,
+                       "host_enqueue_ms_per_launch_set": round(enqueue_ms_per_set, 3)},
         }
+        if plan["rehearsal"]:
+            out["config"]["note"] = (f"REHEARSAL: {world} ranks on fewer GPUs (devices {plan['devices']}); the ranks share GPU time, so this line says "
+                                     "nothing about scaling — it exercises the N-rank code path")
         out["roofline"] = roofline_report(args, world, samples_split, interval_ms, interval_launches, interval_frames, build,
                                           ref_counters, fast_counters, camera_counters, ref_trav_bytes, ref_shade_bytes, trace_ms_frame,
                                           shade_ms / frames, other_ms / frames)
@@ -522,10 +534,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc, W, H, None)
         print(json.dumps(out), flush=True)
 
-    rt.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
+    for st in ranks:
+        st.rt.close()
+    if store:
+        store.close()
 
 
 if __name__ == "__main__":

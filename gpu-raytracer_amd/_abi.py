@@ -11,7 +11,7 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 
-OKRT_ABI_VERSION = 2
+OKRT_ABI_VERSION = 3
 
 # okrt_table slots = the reference's t-registers (ShaderResourceRegisters.h:9-21)
 TABLE_TRI_POS, TABLE_TRI_INFO, TABLE_BVH = 0, 1, 2
@@ -19,7 +19,7 @@ TABLE_OCT, TABLE_SPHERE, TABLE_MESH = 5, 6, 7
 TABLE_DIR_LIGHT, TABLE_POINT_LIGHT, TABLE_SPOT_LIGHT = 8, 9, 10
 TABLE_STRIDE = {0: 36, 1: 132, 2: 36, 5: 48, 6: 84, 7: 232, 8: 32, 9: 32, 10: 48}
 
-OPT_TRAVERSAL, OPT_MAX_BOUNCES, OPT_COUNTERS, OPT_TIMING, OPT_BUILDER, OPT_DEFER, OPT_QUEUE_MEMORY_MB = 0, 1, 2, 3, 4, 5, 6
+OPT_TRAVERSAL, OPT_MAX_BOUNCES, OPT_COUNTERS, OPT_TIMING, OPT_BUILDER, OPT_DEFER, OPT_QUEUE_MEMORY_MB, OPT_DEBUG_FAIL_ALLOC = 0, 1, 2, 3, 4, 5, 6, 7
 BUILDER_HOST, BUILDER_DEVICE = 0, 1
 TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
 BUILD_FLAG_SCALED_INSTANCES, BUILD_FLAG_SHRUNK_INSTANCES = 1, 2
@@ -104,6 +104,12 @@ PRODUCT_ONLY = {
     "mgpu_gather_accum_all": (C.c_int, [C.POINTER(P), C.POINTER(P), U32, U32, P]),
     "mgpu_read_gathered": (C.c_int, [P, P, P]),
     "mgpu_deinterleave": (C.c_int, [P, P, U32, U32, U32, P]),
+    "device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "comm_transport": (C.c_char_p, [P]),
+    "mgpu_reduce_accum": (C.c_int, [P, P, U32, P]),
+    "mgpu_reduce_accum_all": (C.c_int, [C.POINTER(P), C.POINTER(P), U32, U32, P]),
+    "peek_result_rgba8": (C.c_int, [P, P, C.POINTER(U32)]),
+    "frame_size": (C.c_int, [P, C.POINTER(U32), C.POINTER(U32)]),
 }
 KAT_PCG_HASH, KAT_RANDOM_FLOAT, KAT_RAY_SPHERE, KAT_RAY_TRIANGLE, KAT_RAY_AABB, KAT_REFRACT, KAT_SAMPLE_TEXTURE, KAT_SAMPLE_ENV, KAT_CLOSEST_HIT, KAT_CLOSEST_HIT_FAST = range(10)
 KAT_RANDOM_VECTOR, KAT_REFLECTANCE, KAT_REFLECT_DIRECTION, KAT_TRANSPARENCY_BOUNCE, KAT_PRIMARY_RAY = range(10, 15)

@@ -58,6 +58,14 @@ struct okrt_ctx {
     okrt_render_data pendingRd{};
     bool externalFramebuffers = false, externalStream = false;
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
+    // okrt_peek_result_rgba8: two device-side copies of the resolved picture, refreshed alternately at the end of every
+    // launch set once a host has asked for one; the peek copies the newest finished one out on its own stream
+    bool peekOn = false;
+    DeviceBuffer front[2];
+    hipEvent_t frontReady[2] = {nullptr, nullptr}, peekDone[2] = {nullptr, nullptr};
+    bool frontValid[2] = {false, false}, peekRecorded[2] = {false, false};
+    uint32_t frontFrames[2] = {0, 0}, frontNext = 0, launchedFrames = 0;
+    hipStream_t copyStream = nullptr;
     // OKRT_OPT_TIMING: ring of per-render event lists (kernel boundaries, in launch order)
     struct TimedFrame { std::vector<hipEvent_t> ev; int used = 0; bool fast = false; uint32_t frames = 1; };
     std::vector<TimedFrame> ring;
@@ -156,6 +164,8 @@ okrt_status allocFramebuffers(okrt_ctx* c) {
     c->accum = (float4*)c->accumOwn.ptr;
     c->result = (uint32_t*)c->resultOwn.ptr;
     c->externalFramebuffers = false;  // okrt_resize / okrt_set_tile rebind to the library's own buffers (okrt.h: re-bind after them)
+    c->frontValid[0] = c->frontValid[1] = false;  // pictures of another frame size
+    c->launchedFrames = 0;
     if (px) {
         OKRT_HIP(c, hipMemsetAsync(c->accum, 0, px * sizeof(float4), c->stream));
         OKRT_HIP(c, hipMemsetAsync(c->result, 0, px * 4, c->stream));
@@ -261,7 +271,7 @@ namespace okrt {
 okrt_status ctxFrame(okrt_ctx* c, CtxFrame* out) {
     if (!c || !out) return OKRT_ERR_INVALID_ARG;
     OKRT_FLUSH(c);
-    if (!c->W || !c->accum) return fail(c, OKRT_ERR_STATE, "multi-GPU gather before okrt_resize");
+    if (!c->W || (!c->accum && c->tile.rows)) return fail(c, OKRT_ERR_STATE, "multi-GPU gather before okrt_resize");  // (a rank may own zero rows)
     *out = CtxFrame{c->device, c->stream, c->accum, c->tile};
     return OKRT_OK;
 }
@@ -313,8 +323,14 @@ okrt_status okrt_destroy(okrt_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (Table& t : c->tables)
         if (t.dev.ptr) hipFree(t.dev.ptr);
-    for (DeviceBuffer* b : {&c->textures, &c->env, &c->shadeInfo, &c->accumOwn, &c->resultOwn, &c->counters})
+    for (DeviceBuffer* b : {&c->textures, &c->env, &c->shadeInfo, &c->accumOwn, &c->resultOwn, &c->counters, &c->front[0], &c->front[1]})
         if (b->ptr) hipFree(b->ptr);
+    if (c->copyStream) {
+        hipStreamSynchronize(c->copyStream);
+        hipStreamDestroy(c->copyStream);
+    }
+    for (hipEvent_t e : {c->frontReady[0], c->frontReady[1], c->peekDone[0], c->peekDone[1]})
+        if (e) hipEventDestroy(e);
     fastDestroy(c->fast);
     for (hipEvent_t e : {c->evBegin, c->evEnd})
         if (e) hipEventDestroy(e);
@@ -628,6 +644,7 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
     okrt_ctx::TimedFrame* tf = nullptr;
     if (c->timingOn && !c->ring.empty()) {
         tf = &c->ring[c->ringNext];
+        tf->used = 0;  // its events are about to be re-recorded: not a valid measurement again until this launch set succeeded
         const size_t need = 2 * (size_t)(c->maxBounces + 1) + 1;
         while (tf->ev.size() < need) {
             hipEvent_t e;
@@ -661,6 +678,20 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
         c->ringNext = (c->ringNext + 1) % c->ring.size();
         c->ringCount = std::min(c->ringCount + 1, c->ring.size());
     }
+    c->launchedFrames = rd->accumulationEnabled == 1 ? rd->numAccumulationFrames + frames - 1 : 1u;
+    if (c->peekOn && !c->externalFramebuffers) {  // a copy of this launch set's resolved picture for okrt_peek_result_rgba8
+        const uint32_t k = c->frontNext;
+        const size_t bytes = (size_t)c->tile.rows * c->W * 4;
+        if (ensure(c, c->front[k], bytes) == OKRT_OK && bytes) {
+            // (a peek may still be copying the picture this buffer held two launch sets ago: device-side wait, no host stall)
+            if (c->peekRecorded[k]) OKRT_HIP(c, hipStreamWaitEvent(c->stream, c->peekDone[k], 0));
+            OKRT_HIP(c, hipMemcpyAsync(c->front[k].ptr, c->result, bytes, hipMemcpyDeviceToDevice, c->stream));
+            OKRT_HIP(c, hipEventRecord(c->frontReady[k], c->stream));
+            c->frontValid[k] = true;
+            c->frontFrames[k] = c->launchedFrames;
+            c->frontNext = k ^ 1u;
+        }
+    }
     return OKRT_OK;
 }
 
@@ -679,6 +710,51 @@ okrt_status okrt_read_result_rgba8(okrt_ctx* c, uint8_t* dst) {
     OKRT_HIP(c, hipSetDevice(c->device));
     OKRT_HIP(c, hipMemcpyAsync(dst, c->result, (size_t)c->tile.rows * c->W * 4, hipMemcpyDeviceToHost, c->stream));
     OKRT_HIP(c, hipStreamSynchronize(c->stream));
+    return OKRT_OK;
+}
+
+okrt_status okrt_frame_size(const okrt_ctx* c, uint32_t* out_w, uint32_t* out_h) {
+    if (!c || !out_w || !out_h) return OKRT_ERR_INVALID_ARG;
+    *out_w = c->W;
+    *out_h = c->H;
+    return OKRT_OK;
+}
+
+// The newest resolved picture without flushing deferred frames and without waiting for launch sets in flight (okrt.h).
+okrt_status okrt_peek_result_rgba8(okrt_ctx* c, uint8_t* dst, uint32_t* out_frames) {
+    if (!c || !dst) return OKRT_ERR_INVALID_ARG;
+    if (!c->result) return fail(c, OKRT_ERR_STATE, "peek before resize");
+    OKRT_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->tile.rows * c->W * 4;
+    if (out_frames) *out_frames = 0;
+    if (!bytes) return OKRT_OK;
+    if (!c->peekOn && !c->externalFramebuffers) {  // first request: from now on every launch set leaves a copy behind
+        OKRT_HIP(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            OKRT_HIP(c, hipEventCreateWithFlags(&c->frontReady[k], hipEventDisableTiming));
+            OKRT_HIP(c, hipEventCreateWithFlags(&c->peekDone[k], hipEventDisableTiming));
+        }
+        c->peekOn = true;
+    }
+    int pick = -1;
+    for (int t = 0; t < 2 && pick < 0; ++t) {  // newest first
+        const int k = (int)(c->frontNext ^ 1u) ^ t;
+        if (c->peekOn && c->frontValid[k] && c->front[k].bytes == bytes && hipEventQuery(c->frontReady[k]) == hipSuccess) pick = k;
+    }
+    (void)hipGetLastError();  // hipEventQuery reports "not ready" through the error state
+    if (pick < 0) {
+        // nothing finished in a front buffer yet (first call, or right after a resize): the picture as of the last LAUNCHED
+        // set, in stream order — still without executing deferred frames
+        OKRT_HIP(c, hipMemcpyAsync(dst, c->result, bytes, hipMemcpyDeviceToHost, c->stream));
+        OKRT_HIP(c, hipStreamSynchronize(c->stream));
+        if (out_frames) *out_frames = c->launchedFrames;
+        return OKRT_OK;
+    }
+    OKRT_HIP(c, hipMemcpyAsync(dst, c->front[pick].ptr, bytes, hipMemcpyDeviceToHost, c->copyStream));
+    OKRT_HIP(c, hipEventRecord(c->peekDone[pick], c->copyStream));
+    c->peekRecorded[pick] = true;
+    OKRT_HIP(c, hipStreamSynchronize(c->copyStream));
+    if (out_frames) *out_frames = c->frontFrames[pick];
     return OKRT_OK;
 }
 
@@ -723,6 +799,10 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             if (value < 0) return fail(c, OKRT_ERR_INVALID_ARG, "queue memory: MiB >= 0");
             fastSetQueueBudget(&c->fast, (size_t)value << 20);
             c->batchLimit = kMaxFramesPerLaunch;  // probe again from the top
+            return OKRT_OK;
+        case OKRT_OPT_DEBUG_FAIL_ALLOC:
+            if (value < 0 || value > 1000) return fail(c, OKRT_ERR_INVALID_ARG, "debug fail alloc: 0..1000");
+            fastDebugFailAlloc((int)value);
             return OKRT_OK;
         case OKRT_OPT_BUILDER:
             if (value != 0 && value != 1) return fail(c, OKRT_ERR_INVALID_ARG, "builder: 0 (host SAH) or 1 (device PLOC)");
@@ -829,6 +909,7 @@ okrt_status okrt_get_stage_ms(okrt_ctx* c, float out_ms[3], uint32_t* out_frames
     out_ms[0] = out_ms[1] = out_ms[2] = 0.f;
     *out_frames = 0;
     for (size_t i = 0; i < c->ringCount; ++i) {
+        if (c->ring[i].used < 2) continue;  // a slot whose launch set was refused or failed
         float st[3];
         okrt_status s = frameStages(c, c->ring[i], st);
         if (s != OKRT_OK) return s;
@@ -851,7 +932,7 @@ okrt_status okrt_get_interval_ms(okrt_ctx* c, float* out_ms, uint32_t capacity, 
     for (uint32_t k = 0; k < capacity && k < (uint32_t)n; ++k) out_ms[k] = 0.f;
     for (size_t i = 0; i < c->ringCount; ++i) {
         const okrt_ctx::TimedFrame& f = c->ring[i];
-        if (f.used != newest.used || f.fast != newest.fast) continue;
+        if (f.used != newest.used || f.fast != newest.fast || f.frames != newest.frames) continue;  // only launch sets of the newest one's shape
         OKRT_HIP(c, hipEventSynchronize(f.ev[f.used - 1]));
         for (int k = 0; k < n; ++k) {
             float ms = 0.f;
@@ -912,7 +993,9 @@ const okrt_api* okrt_get_api(void) {
                                  okrt_timer_elapsed_ms, okrt_last_render_ms, okrt_get_stage_ms, okrt_get_interval_ms,
                                  okrt_debug_kat,       okrt_comm_unique_id, okrt_comm_create, okrt_comm_create_all,
                                  okrt_comm_destroy,    okrt_comm_last_error, okrt_mgpu_gather_accum, okrt_mgpu_gather_accum_all,
-                                 okrt_mgpu_read_gathered, okrt_mgpu_deinterleave};
+                                 okrt_mgpu_read_gathered, okrt_mgpu_deinterleave,
+                                 okrt_device_count,    okrt_comm_transport, okrt_mgpu_reduce_accum, okrt_mgpu_reduce_accum_all,
+                                 okrt_peek_result_rgba8, okrt_frame_size};
     return &api;
 }
 

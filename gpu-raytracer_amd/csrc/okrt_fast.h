@@ -76,6 +76,7 @@ struct DeviceArray {
         if (headroom) n += n / 8;
         hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
         if (e != hipSuccess) {
+            (void)hipGetLastError();  // not left behind for an unrelated later check
             p = nullptr;
             err = std::string("hipMalloc: ") + hipGetErrorString(e);
             return false;
@@ -120,6 +121,8 @@ bool fastKat(const FastScene* scene, const SceneView& s, uint32_t n, const float
              hipStream_t stream, std::string& err);
 // upper bound for the wavefront queues of one launch set (0 = none): larger sets are refused and the caller halves them
 void fastSetQueueBudget(FastScene** scene, size_t bytes);
+// test hook (OKRT_OPT_DEBUG_FAIL_ALLOC): the nth queue allocation from now on reports out-of-memory
+void fastDebugFailAlloc(int nth);
 // copies the structure back to the host (tests); either pointer may be null
 bool fastReadStructure(const FastScene* scene, void* nodes, uint32_t nodeCapacity, void* tris, uint32_t triCapacity, hipStream_t stream, std::string& err);
 void fastDestroy(FastScene* scene);

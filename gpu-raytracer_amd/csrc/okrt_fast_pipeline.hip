@@ -44,13 +44,21 @@ using namespace fastdetail;
 
 namespace {
 
+// OKRT_OPT_DEBUG_FAIL_ALLOC: the n-th queue allocation from now on fails as the allocator would (test hook for the
+// launch-set split; 0 = off)
+int g_failAllocIn = 0;
+
 template <class T>
 bool devAlloc(T** p, size_t n, std::string& err) {
     if (*p) hipFree(*p);
     *p = nullptr;
     if (!n) return true;
-    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    hipError_t e = (g_failAllocIn > 0 && --g_failAllocIn == 0) ? hipErrorOutOfMemory : hipMalloc((void**)p, n * sizeof(T));
     if (e != hipSuccess) {
+        // a failed hipMalloc stays behind as the thread's "last error": taken out here, or the hipGetLastError() after the
+        // NEXT (successful, smaller) launch set would report this one
+        (void)hipGetLastError();
+        *p = nullptr;
         err = std::string("hipMalloc: ") + hipGetErrorString(e);
         return false;
     }
@@ -166,6 +174,8 @@ bool fastKat(const FastScene* fs, const SceneView& s, uint32_t n, const float* i
     launchFastKat(stream, fs->nodes.p, fs->tris.p, s, n, in, inFloats, out, outFloats);
     return true;
 }
+
+void fastDebugFailAlloc(int nth) { g_failAllocIn = nth; }
 
 void fastSetQueueBudget(FastScene** scene, size_t bytes) {
     if (!*scene) *scene = new FastScene();

@@ -5,9 +5,17 @@
 //
 // RCCL is bound at run time (dlopen of librccl.so.1): libokrt.so has no link-time dependency on it, and a process that
 // already carries an RCCL (PyTorch) is not handed a second copy unless it asks for a communicator here.
+//
+// Two transports sit under the same entry points:
+//   rccl  one ncclSend per peer / one ncclRecv per peer on the root inside ONE group, on the contexts' streams (default);
+//   copy  okrt_comm_create_all only (one process owns every context): the root's stream waits on an event of each peer's
+//         stream and pulls the tile with hipMemcpyPeerAsync (SDMA over xGMI, or a plain device copy when two contexts
+//         share a GPU). Chosen when two contexts share a device — RCCL refuses duplicate devices — which is how an
+//         N-rank split is rehearsed on fewer GPUs, or with OKRT_MGPU_TRANSPORT=copy.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -29,6 +37,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -58,6 +67,7 @@ Rccl& rccl() {
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.Reduce = (decltype(r.Reduce))sym("ncclReduce");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
     return r;
@@ -76,6 +86,16 @@ __global__ __launch_bounds__(256) void deinterleaveKernel(const float4* __restri
     full[i] = tiles[((size_t)rank * strideRows + local) * W + x];
 }
 
+// Samples split (okrt_mgpu_reduce_accum with the copy transport): full += part, element by element.
+__global__ __launch_bounds__(256) void addFramesKernel(float4* __restrict__ full, const float4* __restrict__ part, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 a = full[i];
+    const float4 b = part[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    full[i] = a;
+}
+
 uint32_t rowsOf(uint32_t H, uint32_t stripeRows, uint32_t idx, uint32_t stride) {
     uint32_t rows = 0;
     for (uint32_t s = idx; (uint64_t)s * stripeRows < H; s += stride) rows += (H - s * stripeRows) < stripeRows ? (H - s * stripeRows) : stripeRows;
@@ -85,10 +105,12 @@ uint32_t rowsOf(uint32_t H, uint32_t stripeRows, uint32_t idx, uint32_t stride) 
 }  // namespace
 
 struct okrt_comm {
-    ncclComm_t comm = nullptr;  // null for a communicator of one rank
+    ncclComm_t comm = nullptr;  // null for a communicator of one rank and for the copy transport
     uint32_t rank = 0, nranks = 1;
     int device = 0;
-    float4* staging = nullptr;  // root: nranks tiles of maxRows rows
+    bool copyTransport = false;
+    hipEvent_t ready = nullptr, done = nullptr;  // copy transport: "my frames are rendered" / "the root has my tile"
+    float4* staging = nullptr;  // root: nranks tiles of maxRows rows (gather) or one full frame (reduce, copy transport)
     size_t stagingBytes = 0;
     float4* full = nullptr;     // root: library-owned full frame
     size_t fullBytes = 0;
@@ -109,66 +131,129 @@ bool ncclOk(okrt_comm* c, ncclResult_t r, const char* what) {
     return false;
 }
 
-// Validates that the context's tile is the rank's share of an nranks-way split; returns its geometry.
-okrt_status tileOf(okrt_ctx* ctx, okrt_comm* comm, CtxFrame* f) {
+// Validates that the context's tile is the rank's share of an nranks-way split (or, for the samples split, the whole
+// frame); returns its geometry.
+okrt_status tileOf(okrt_ctx* ctx, okrt_comm* comm, CtxFrame* f, bool wholeFrame) {
     okrt_status s = ctxFrame(ctx, f);
     if (s != OKRT_OK) return s;
-    if (f->tile.stripeStride != comm->nranks || f->tile.stripeIndex != comm->rank)
+    if (wholeFrame) {
+        if (f->tile.rows != f->tile.H) return ctxFail(ctx, OKRT_ERR_STATE, "mgpu reduce: the samples split needs the full-frame tile on every rank");
+    } else if (f->tile.stripeStride != comm->nranks || f->tile.stripeIndex != comm->rank) {
         return ctxFail(ctx, OKRT_ERR_STATE, "mgpu gather: the context's tile is not okrt_set_tile(stripe_rows, rank, nranks) of this communicator");
+    }
     if (f->device != comm->device) return ctxFail(ctx, OKRT_ERR_STATE, "mgpu gather: communicator and context live on different devices");
     return OKRT_OK;
 }
 
-okrt_status ensureRootBuffers(okrt_ctx* ctx, okrt_comm* comm, const CtxFrame& f, bool needFull) {
-    const uint32_t maxRows = rowsOf(f.tile.H, f.tile.stripeRows, 0, comm->nranks);  // rank 0 owns the most rows
-    const size_t stagingBytes = (size_t)comm->nranks * maxRows * f.tile.W * sizeof(float4);
-    const size_t fullBytes = (size_t)f.tile.H * f.tile.W * sizeof(float4);
+okrt_status ensureRootBuffers(okrt_ctx* ctx, okrt_comm* comm, size_t stagingBytes, size_t fullBytes) {
     if (comm->stagingBytes < stagingBytes) {
         if (comm->staging) hipFree(comm->staging);
         comm->staging = nullptr;
         comm->stagingBytes = 0;
-        if (hipMalloc((void**)&comm->staging, stagingBytes) != hipSuccess) return ctxFail(ctx, OKRT_ERR_OOM, "mgpu gather: staging allocation failed");
+        if (hipMalloc((void**)&comm->staging, stagingBytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return ctxFail(ctx, OKRT_ERR_OOM, "mgpu gather: staging allocation failed");
+        }
         comm->stagingBytes = stagingBytes;
     }
-    if (needFull && comm->fullBytes < fullBytes) {
+    if (comm->fullBytes < fullBytes) {
         if (comm->full) hipFree(comm->full);
         comm->full = nullptr;
         comm->fullBytes = 0;
-        if (hipMalloc((void**)&comm->full, fullBytes) != hipSuccess) return ctxFail(ctx, OKRT_ERR_OOM, "mgpu gather: frame allocation failed");
+        if (hipMalloc((void**)&comm->full, fullBytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return ctxFail(ctx, OKRT_ERR_OOM, "mgpu gather: frame allocation failed");
+        }
         comm->fullBytes = fullBytes;
     }
     return OKRT_OK;
 }
 
-// The sends / receives of one rank (inside the caller's RCCL group) and, on the root, the copy of its own tile.
-okrt_status postRank(okrt_ctx* ctx, okrt_comm* comm, const CtxFrame& f, uint32_t root) {
-    const uint32_t maxRows = rowsOf(f.tile.H, f.tile.stripeRows, 0, comm->nranks);
-    const size_t rowFloats = (size_t)f.tile.W * 4;
-    if (comm->rank == root) {
-        if (hipMemcpyAsync(comm->staging + (size_t)root * maxRows * f.tile.W, f.accum, (size_t)f.tile.rows * rowFloats * sizeof(float), hipMemcpyDeviceToDevice,
-                           f.stream) != hipSuccess)
-            return ctxFail(ctx, OKRT_ERR_DEVICE, "mgpu gather: copy of the root's own tile failed");
-        for (uint32_t r = 0; r < comm->nranks; ++r) {
-            if (r == root) continue;
-            const uint32_t rows = rowsOf(f.tile.H, f.tile.stripeRows, r, comm->nranks);
-            if (rows && !ncclOk(comm, rccl().Recv(comm->staging + (size_t)r * maxRows * f.tile.W, rows * rowFloats, ncclFloat, (int)r, comm->comm, f.stream), "ncclRecv"))
-                return ctxFail(ctx, OKRT_ERR_DEVICE, comm->err);
-        }
-    } else if (f.tile.rows) {
-        if (!ncclOk(comm, rccl().Send(f.accum, f.tile.rows * rowFloats, ncclFloat, (int)root, comm->comm, f.stream), "ncclSend"))
-            return ctxFail(ctx, OKRT_ERR_DEVICE, comm->err);
+// What the two collectives share: every context and communicator checked BEFORE anything is posted (nothing that can
+// fail for a reason other than the transport itself is left inside the RCCL group), the root found, its buffers sized.
+struct Plan {
+    std::vector<CtxFrame> fr;
+    uint32_t rootSlot, maxRows;
+    bool copy;
+};
+
+okrt_status planCollective(okrt_ctx* const* ctxs, okrt_comm* const* comms, uint32_t n, uint32_t root, bool wholeFrame, bool needFull, Plan* p) {
+    if (!ctxs || !comms || !n) return OKRT_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < n; ++k)
+        if (!ctxs[k] || !comms[k]) return OKRT_ERR_INVALID_ARG;
+    const uint32_t nranks = comms[0]->nranks;
+    // one thread drives either ONE rank of the communicator (one process per GPU) or ALL of them (one process, n GPUs):
+    // with a subset the group would post sends without their receive and hang the peers
+    if (n != 1 && n != nranks) return ctxFail(ctxs[0], OKRT_ERR_INVALID_ARG, "mgpu: pass one rank or all " + std::to_string(nranks) + " ranks of the communicator");
+    p->fr.resize(n);
+    p->rootSlot = n;
+    p->copy = comms[0]->copyTransport;
+    if (p->copy && n != nranks) return ctxFail(ctxs[0], OKRT_ERR_INVALID_ARG, "mgpu: the copy transport needs all ranks in one call (okrt_mgpu_*_all)");
+    std::vector<char> seen(nranks, 0);
+    for (uint32_t k = 0; k < n; ++k) {
+        if (comms[k]->nranks != nranks || comms[k]->copyTransport != p->copy) return ctxFail(ctxs[k], OKRT_ERR_INVALID_ARG, "mgpu: communicators of different groups");
+        if (root >= nranks) return ctxFail(ctxs[k], OKRT_ERR_INVALID_ARG, "mgpu gather: root out of range");
+        if (seen[comms[k]->rank]++) return ctxFail(ctxs[k], OKRT_ERR_INVALID_ARG, "mgpu: rank " + std::to_string(comms[k]->rank) + " passed twice");
+        okrt_status s = tileOf(ctxs[k], comms[k], &p->fr[k], wholeFrame);
+        if (s != OKRT_OK) return s;
+        if (p->fr[k].tile.W != p->fr[0].tile.W || p->fr[k].tile.H != p->fr[0].tile.H || (!wholeFrame && p->fr[k].tile.stripeRows != p->fr[0].tile.stripeRows))
+            return ctxFail(ctxs[k], OKRT_ERR_STATE, "mgpu gather: ranks disagree about the frame size or the stripe height");
+        if (comms[k]->rank == root) p->rootSlot = k;
+    }
+    const TileView& t = p->fr[0].tile;
+    p->maxRows = wholeFrame ? t.H : rowsOf(t.H, t.stripeRows, 0, nranks);  // rank 0 owns the most rows
+    if (p->rootSlot < n) {
+        if (hipSetDevice(p->fr[p->rootSlot].device) != hipSuccess) return ctxFail(ctxs[p->rootSlot], OKRT_ERR_DEVICE, "hipSetDevice");
+        const size_t frameBytes = (size_t)t.H * t.W * sizeof(float4);
+        const size_t staging = wholeFrame ? (p->copy ? frameBytes : 0) : (size_t)nranks * p->maxRows * t.W * sizeof(float4);
+        okrt_status s = ensureRootBuffers(ctxs[p->rootSlot], comms[p->rootSlot], staging, needFull ? frameBytes : 0);
+        if (s != OKRT_OK) return s;
     }
     return OKRT_OK;
 }
 
-okrt_status finishRoot(okrt_ctx* ctx, okrt_comm* comm, const CtxFrame& f, void* fullFrameDev) {
-    const uint32_t maxRows = rowsOf(f.tile.H, f.tile.stripeRows, 0, comm->nranks);
+// copy transport: the root's stream pulls `bytes` from a peer's buffer once the peer's stream has reached this point.
+okrt_status pullFromPeer(okrt_ctx* rootCtx, const CtxFrame& rootF, okrt_comm* peer, const CtxFrame& peerF, void* dst, const void* src, size_t bytes) {
+    hipError_t e = hipSetDevice(peerF.device);
+    if (e == hipSuccess) e = hipEventRecord(peer->ready, peerF.stream);
+    if (e == hipSuccess) e = hipSetDevice(rootF.device);
+    if (e == hipSuccess) e = hipStreamWaitEvent(rootF.stream, peer->ready, 0);
+    if (e == hipSuccess)
+        e = peerF.device == rootF.device ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, rootF.stream)
+                                         : hipMemcpyPeerAsync(dst, rootF.device, src, peerF.device, bytes, rootF.stream);
+    if (e != hipSuccess) return ctxFail(rootCtx, OKRT_ERR_DEVICE, std::string("mgpu copy transport: ") + hipGetErrorString(e));
+    return OKRT_OK;
+}
+// ... and afterwards every peer's stream waits until the root holds its data (it may render into that buffer again).
+okrt_status releasePeers(okrt_ctx* rootCtx, const Plan& p, okrt_comm* const* comms) {
+    const CtxFrame& rf = p.fr[p.rootSlot];
+    hipError_t e = hipSetDevice(rf.device);
+    if (e == hipSuccess) e = hipEventRecord(comms[p.rootSlot]->done, rf.stream);
+    for (uint32_t k = 0; k < p.fr.size() && e == hipSuccess; ++k) {
+        if (k == p.rootSlot) continue;
+        e = hipSetDevice(p.fr[k].device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p.fr[k].stream, comms[p.rootSlot]->done, 0);
+    }
+    if (e != hipSuccess) return ctxFail(rootCtx, OKRT_ERR_DEVICE, std::string("mgpu copy transport: ") + hipGetErrorString(e));
+    return OKRT_OK;
+}
+
+okrt_status deinterleaveOnRoot(okrt_ctx* ctx, okrt_comm* comm, const CtxFrame& f, uint32_t maxRows, void* fullFrameDev) {
     float4* dst = fullFrameDev ? (float4*)fullFrameDev : comm->full;
     const size_t px = (size_t)f.tile.W * f.tile.H;
+    if (hipSetDevice(f.device) != hipSuccess) return ctxFail(ctx, OKRT_ERR_DEVICE, "hipSetDevice");
     hipLaunchKernelGGL(deinterleaveKernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, f.stream, comm->staging, dst, f.tile.W, f.tile.H, comm->nranks,
                        f.tile.stripeRows, maxRows);
     if (hipGetLastError() != hipSuccess) return ctxFail(ctx, OKRT_ERR_DEVICE, "mgpu gather: de-interleave launch failed");
     return OKRT_OK;
+}
+
+okrt_comm* newComm(uint32_t rank, uint32_t nranks, int device) {
+    okrt_comm* c = new okrt_comm();
+    c->rank = rank;
+    c->nranks = nranks;
+    c->device = device;
+    return c;
 }
 
 }  // namespace
@@ -176,6 +261,22 @@ okrt_status finishRoot(okrt_ctx* ctx, okrt_comm* comm, const CtxFrame& f, void* 
 extern "C" {
 
 const char* okrt_comm_last_error(const okrt_comm* comm) { return comm ? comm->err.c_str() : g_commCreateError.c_str(); }
+
+const char* okrt_comm_transport(const okrt_comm* comm) {
+    if (!comm) return "";
+    return comm->nranks == 1 ? "single" : comm->copyTransport ? "copy" : "rccl";
+}
+
+okrt_status okrt_device_count(int* out_count) {
+    if (!out_count) return OKRT_ERR_INVALID_ARG;
+    *out_count = 0;
+    if (hipGetDeviceCount(out_count) != hipSuccess) {
+        (void)hipGetLastError();
+        *out_count = 0;
+        return OKRT_ERR_DEVICE;
+    }
+    return OKRT_OK;
+}
 
 okrt_status okrt_comm_unique_id(uint8_t out_id[OKRT_COMM_ID_BYTES]) {
     static_assert(OKRT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
@@ -194,10 +295,7 @@ okrt_status okrt_comm_create(okrt_ctx* ctx, const uint8_t id[OKRT_COMM_ID_BYTES]
     CtxFrame f;
     okrt_status s = ctxFrame(ctx, &f);
     if (s != OKRT_OK) return commFail(nullptr, s, "comm_create: the context needs a frame size first (okrt_resize)");
-    okrt_comm* c = new okrt_comm();
-    c->rank = rank;
-    c->nranks = nranks;
-    c->device = f.device;
+    okrt_comm* c = newComm(rank, nranks, f.device);
     if (nranks > 1) {
         Rccl& r = rccl();
         if (!r.error.empty()) {
@@ -219,27 +317,46 @@ okrt_status okrt_comm_create(okrt_ctx* ctx, const uint8_t id[OKRT_COMM_ID_BYTES]
 okrt_status okrt_comm_create_all(okrt_ctx* const* ctxs, uint32_t n, okrt_comm** out) {
     if (!ctxs || !out || !n) return commFail(nullptr, OKRT_ERR_INVALID_ARG, "comm_create_all: bad argument");
     std::vector<int> devs(n);
+    bool shared = false;
     for (uint32_t r = 0; r < n; ++r) {
         out[r] = nullptr;
         CtxFrame f;
         okrt_status s = ctxs[r] ? ctxFrame(ctxs[r], &f) : OKRT_ERR_INVALID_ARG;
         if (s != OKRT_OK) return commFail(nullptr, s, "comm_create_all: context " + std::to_string(r) + " is missing or has no frame size yet");
         devs[r] = f.device;
-        for (uint32_t q = 0; q < r; ++q)
-            if (devs[q] == devs[r]) return commFail(nullptr, OKRT_ERR_INVALID_ARG, "comm_create_all: two contexts share device " + std::to_string(devs[r]));
+        for (uint32_t q = 0; q < r; ++q) {
+            if (ctxs[q] == ctxs[r]) return commFail(nullptr, OKRT_ERR_INVALID_ARG, "comm_create_all: context " + std::to_string(r) + " passed twice");
+            shared = shared || devs[q] == devs[r];
+        }
     }
+    // RCCL cannot place two ranks on one device: contexts that share a GPU (an N-rank split rehearsed on fewer GPUs)
+    // are joined by the copy transport instead; OKRT_MGPU_TRANSPORT=copy selects it for distinct devices too
+    const char* env = getenv("OKRT_MGPU_TRANSPORT");
+    const bool copy = n > 1 && (shared || (env && std::strcmp(env, "copy") == 0));
     std::vector<ncclComm_t> comms(n, nullptr);
-    if (n > 1) {
+    if (n > 1 && !copy) {
         Rccl& r = rccl();
         if (!r.error.empty()) return commFail(nullptr, OKRT_ERR_DEVICE, r.error);
         if (!ncclOk(nullptr, r.CommInitAll(comms.data(), (int)n, devs.data()), "ncclCommInitAll")) return OKRT_ERR_DEVICE;
     }
     for (uint32_t r = 0; r < n; ++r) {
-        okrt_comm* c = new okrt_comm();
+        okrt_comm* c = newComm(r, n, devs[r]);
         c->comm = comms[r];
-        c->rank = r;
-        c->nranks = n;
-        c->device = devs[r];
+        c->copyTransport = copy;
+        if (copy) {
+            hipError_t e = hipSetDevice(devs[r]);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                commFail(nullptr, OKRT_ERR_DEVICE, std::string("comm_create_all: ") + hipGetErrorString(e));
+                delete c;
+                for (uint32_t q = 0; q < r; ++q) {
+                    okrt_comm_destroy(out[q]);
+                    out[q] = nullptr;
+                }
+                return OKRT_ERR_DEVICE;
+            }
+        }
         out[r] = c;
     }
     return OKRT_OK;
@@ -249,6 +366,8 @@ okrt_status okrt_comm_destroy(okrt_comm* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
     hipSetDevice(c->device);
     if (c->comm) rccl().CommDestroy(c->comm);
+    if (c->ready) hipEventDestroy(c->ready);
+    if (c->done) hipEventDestroy(c->done);
     if (c->staging) hipFree(c->staging);
     if (c->full) hipFree(c->full);
     delete c;
@@ -256,41 +375,91 @@ okrt_status okrt_comm_destroy(okrt_comm* c) {
 }
 
 okrt_status okrt_mgpu_gather_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* comms, uint32_t n, uint32_t root, void* fullFrameDev) {
-    if (!ctxs || !comms || !n) return OKRT_ERR_INVALID_ARG;
-    std::vector<CtxFrame> fr(n);
-    uint32_t rootSlot = n;
-    for (uint32_t k = 0; k < n; ++k) {
-        if (!ctxs[k] || !comms[k]) return OKRT_ERR_INVALID_ARG;
-        if (root >= comms[k]->nranks) return ctxFail(ctxs[k], OKRT_ERR_INVALID_ARG, "mgpu gather: root out of range");
-        okrt_status s = tileOf(ctxs[k], comms[k], &fr[k]);
-        if (s != OKRT_OK) return s;
-        if (fr[k].tile.W != fr[0].tile.W || fr[k].tile.H != fr[0].tile.H || fr[k].tile.stripeRows != fr[0].tile.stripeRows)
-            return ctxFail(ctxs[k], OKRT_ERR_STATE, "mgpu gather: ranks disagree about the frame size or the stripe height");
-        if (comms[k]->rank == root) rootSlot = k;
-    }
-    if (rootSlot < n) {
-        if (hipSetDevice(fr[rootSlot].device) != hipSuccess) return ctxFail(ctxs[rootSlot], OKRT_ERR_DEVICE, "hipSetDevice");
-        okrt_status s = ensureRootBuffers(ctxs[rootSlot], comms[rootSlot], fr[rootSlot], fullFrameDev == nullptr);
-        if (s != OKRT_OK) return s;
-    }
-    const bool multi = comms[0]->nranks > 1;
-    if (multi && !ncclOk(comms[0], rccl().GroupStart(), "ncclGroupStart")) return ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
-    okrt_status st = OKRT_OK;
-    for (uint32_t k = 0; k < n && st == OKRT_OK; ++k) {
-        if (hipSetDevice(fr[k].device) != hipSuccess) st = ctxFail(ctxs[k], OKRT_ERR_DEVICE, "hipSetDevice");
-        else st = postRank(ctxs[k], comms[k], fr[k], root);
-    }
-    if (multi && !ncclOk(comms[0], rccl().GroupEnd(), "ncclGroupEnd") && st == OKRT_OK) st = ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
+    Plan p;
+    okrt_status st = planCollective(ctxs, comms, n, root, false, fullFrameDev == nullptr, &p);
     if (st != OKRT_OK) return st;
-    if (rootSlot < n) {
-        if (hipSetDevice(fr[rootSlot].device) != hipSuccess) return ctxFail(ctxs[rootSlot], OKRT_ERR_DEVICE, "hipSetDevice");
-        return finishRoot(ctxs[rootSlot], comms[rootSlot], fr[rootSlot], fullFrameDev);
+    const uint32_t nranks = comms[0]->nranks;
+    const TileView& t0 = p.fr[0].tile;
+    const size_t rowBytes = (size_t)t0.W * sizeof(float4);
+    if (p.rootSlot < n) {  // the root's own tile: a device copy, outside any group
+        const CtxFrame& rf = p.fr[p.rootSlot];
+        if (rf.tile.rows && (hipSetDevice(rf.device) != hipSuccess ||
+                             hipMemcpyAsync(comms[p.rootSlot]->staging + (size_t)root * p.maxRows * t0.W, rf.accum, rf.tile.rows * rowBytes, hipMemcpyDeviceToDevice, rf.stream) != hipSuccess))
+            return ctxFail(ctxs[p.rootSlot], OKRT_ERR_DEVICE, "mgpu gather: copy of the root's own tile failed");
     }
-    return OKRT_OK;
+    if (nranks > 1 && p.copy) {
+        for (uint32_t k = 0; k < n; ++k) {
+            if (k == p.rootSlot || !p.fr[k].tile.rows) continue;
+            st = pullFromPeer(ctxs[p.rootSlot], p.fr[p.rootSlot], comms[k], p.fr[k], comms[p.rootSlot]->staging + (size_t)comms[k]->rank * p.maxRows * t0.W, p.fr[k].accum,
+                              p.fr[k].tile.rows * rowBytes);
+            if (st != OKRT_OK) return st;
+        }
+    } else if (nranks > 1) {
+        // ONE group around every send and receive this thread posts; only RCCL calls inside it
+        if (!ncclOk(comms[0], rccl().GroupStart(), "ncclGroupStart")) return ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
+        for (uint32_t k = 0; k < n && st == OKRT_OK; ++k) {
+            okrt_comm* c = comms[k];
+            const CtxFrame& f = p.fr[k];
+            if (k == p.rootSlot) {
+                for (uint32_t r = 0; r < nranks && st == OKRT_OK; ++r) {
+                    if (r == root) continue;
+                    const uint32_t rows = rowsOf(t0.H, t0.stripeRows, r, nranks);
+                    if (rows && !ncclOk(c, rccl().Recv(c->staging + (size_t)r * p.maxRows * t0.W, (size_t)rows * t0.W * 4, ncclFloat, (int)r, c->comm, f.stream), "ncclRecv"))
+                        st = ctxFail(ctxs[k], OKRT_ERR_DEVICE, c->err);
+                }
+            } else if (f.tile.rows) {
+                if (!ncclOk(c, rccl().Send(f.accum, (size_t)f.tile.rows * t0.W * 4, ncclFloat, (int)root, c->comm, f.stream), "ncclSend")) st = ctxFail(ctxs[k], OKRT_ERR_DEVICE, c->err);
+            }
+        }
+        if (!ncclOk(comms[0], rccl().GroupEnd(), "ncclGroupEnd") && st == OKRT_OK) st = ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
+        if (st != OKRT_OK) return st;
+    }
+    if (p.rootSlot < n) {
+        st = deinterleaveOnRoot(ctxs[p.rootSlot], comms[p.rootSlot], p.fr[p.rootSlot], p.maxRows, fullFrameDev);
+        if (st == OKRT_OK && nranks > 1 && p.copy) st = releasePeers(ctxs[p.rootSlot], p, comms);
+    }
+    return st;
 }
 
 okrt_status okrt_mgpu_gather_accum(okrt_ctx* ctx, okrt_comm* comm, uint32_t root, void* fullFrameDev) {
     return okrt_mgpu_gather_accum_all(&ctx, &comm, 1, root, fullFrameDev);
+}
+
+// Samples split: every rank holds a whole-frame accumulation of its own block of frame indices; their SUM lands on the
+// root (the library-owned frame, or full_frame_dev). One ncclReduce per rank inside one group; copy transport: the root
+// pulls each peer's frame into staging and adds it.
+okrt_status okrt_mgpu_reduce_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* comms, uint32_t n, uint32_t root, void* fullFrameDev) {
+    Plan p;
+    okrt_status st = planCollective(ctxs, comms, n, root, true, fullFrameDev == nullptr, &p);
+    if (st != OKRT_OK) return st;
+    const uint32_t nranks = comms[0]->nranks;
+    const TileView& t0 = p.fr[0].tile;
+    const size_t px = (size_t)t0.W * t0.H;
+    float4* dst = nullptr;
+    if (p.rootSlot < n) dst = fullFrameDev ? (float4*)fullFrameDev : comms[p.rootSlot]->full;
+    if (nranks == 1 || p.copy) {
+        const CtxFrame& rf = p.fr[p.rootSlot];
+        if (hipSetDevice(rf.device) != hipSuccess || hipMemcpyAsync(dst, rf.accum, px * sizeof(float4), hipMemcpyDeviceToDevice, rf.stream) != hipSuccess)
+            return ctxFail(ctxs[p.rootSlot], OKRT_ERR_DEVICE, "mgpu reduce: copy of the root's own frame failed");
+        for (uint32_t k = 0; k < n && nranks > 1; ++k) {  // rank order: the sum is deterministic
+            if (k == p.rootSlot) continue;
+            st = pullFromPeer(ctxs[p.rootSlot], rf, comms[k], p.fr[k], comms[p.rootSlot]->staging, p.fr[k].accum, px * sizeof(float4));
+            if (st != OKRT_OK) return st;
+            hipLaunchKernelGGL(addFramesKernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, rf.stream, dst, comms[p.rootSlot]->staging, px);
+            if (hipGetLastError() != hipSuccess) return ctxFail(ctxs[p.rootSlot], OKRT_ERR_DEVICE, "mgpu reduce: launch failed");
+        }
+        return nranks > 1 ? releasePeers(ctxs[p.rootSlot], p, comms) : OKRT_OK;
+    }
+    if (!ncclOk(comms[0], rccl().GroupStart(), "ncclGroupStart")) return ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
+    for (uint32_t k = 0; k < n && st == OKRT_OK; ++k)
+        if (!ncclOk(comms[k], rccl().Reduce(p.fr[k].accum, k == p.rootSlot ? (void*)dst : nullptr, px * 4, ncclFloat, ncclSum, (int)root, comms[k]->comm, p.fr[k].stream), "ncclReduce"))
+            st = ctxFail(ctxs[k], OKRT_ERR_DEVICE, comms[k]->err);
+    if (!ncclOk(comms[0], rccl().GroupEnd(), "ncclGroupEnd") && st == OKRT_OK) st = ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
+    return st;
+}
+
+okrt_status okrt_mgpu_reduce_accum(okrt_ctx* ctx, okrt_comm* comm, uint32_t root, void* fullFrameDev) {
+    return okrt_mgpu_reduce_accum_all(&ctx, &comm, 1, root, fullFrameDev);
 }
 
 okrt_status okrt_mgpu_read_gathered(okrt_ctx* ctx, okrt_comm* comm, float* dst) {

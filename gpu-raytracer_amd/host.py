@@ -128,6 +128,18 @@ class Context:
         self._ck(self.fns.read_result_rgba8(self.h, _ptr(out)), "read_result")
         return out
 
+    def peek_result(self):
+        """(rgba8 picture, numAccumulationFrames it shows): okrt_peek_result_rgba8 — no flush of deferred frames."""
+        out = np.zeros((self.tile_rows(), self.W, 4), dtype=np.uint8)
+        n = U32()
+        self._ck(self.fns.peek_result_rgba8(self.h, _ptr(out), C.byref(n)), "peek_result")
+        return out, n.value
+
+    def frame_size(self):
+        w, h = U32(), U32()
+        self._ck(self.fns.frame_size(self.h, C.byref(w), C.byref(h)), "frame_size")
+        return w.value, h.value
+
     def set_option(self, opt, value):
         self._ck(self.fns.set_option(self.h, opt, int(value)), "set_option")
 

@@ -13,7 +13,9 @@ namespace Okay {
 void initiateDX11();   // DX11.cpp:21-42: nothing to create; contexts are made by RayTracer::initiate
 void shutdownDX11();
 // DX11.cpp:196-230: *ppOutData = new unsigned char[W * H * 4] (release with OKAY_DELETE_ARRAY) holding the RGBA8 pixels
-// of the texture, row 0 = top; zeros when no RayTracer has rendered into it.
+// of the texture, row 0 = top; zeros when no RayTracer has rendered into it. The buffer has the TEXTURE's size; pixels are
+// read at the rendering context's size and the overlap is copied (they differ between RenderTexture::resize and
+// RayTracer::onResize).
 void getCPUTextureData(ID3D11Texture2D* pSourceTexture, void** ppOutData);
 }  // namespace Okay
 
@@ -23,4 +25,7 @@ namespace okay_compat {
 void setDeviceApi(const okrt_api* api, int device = 0);
 const okrt_api* deviceApi();
 int deviceOrdinal();
+// true: Okay::getCPUTextureData returns the newest RESOLVED picture (okrt_peek_result_rgba8) instead of executing the
+// deferred frames first — for a loop that reads the texture back every frame to present it; screenshots keep `false`.
+void setReadbackWithoutFlush(bool on);
 }  // namespace okay_compat

@@ -23,9 +23,10 @@ RayTracer::RayTracer(const RenderTexture& target, const ResourceManager& resourc
 RayTracer::~RayTracer() { shutdown(); }
 
 void RayTracer::shutdown() {
-    if (m_pTargetTexture && *m_pTargetTexture->getBuffer()) {
-        (*m_pTargetTexture->getBuffer())->ctx = nullptr;
-        (*m_pTargetTexture->getBuffer())->api = nullptr;
+    if (m_pixels) {  // the target texture may already be gone (it is not ours): cut the link from this side only
+        m_pixels->ctx = nullptr;
+        m_pixels->api = nullptr;
+        m_pixels.reset();
     }
     m_impl.reset();
     m_scene.reset();
@@ -72,8 +73,10 @@ void RayTracer::initiate(const RenderTexture& target, const ResourceManager& res
     }
     ID3D11Texture2D* buffer = *target.getBuffer();
     if (buffer) {  // Okay::getCPUTextureData(*target.getBuffer(), ...) now reads this context's result
-        buffer->api = api;
-        buffer->ctx = m_impl->deviceContext();
+        m_pixels = std::make_shared<okay_compat::PixelSource>();
+        m_pixels->api = api;
+        m_pixels->ctx = m_impl->deviceContext();
+        buffer->pixels = m_pixels;
     }
     mirrorTables();
 }

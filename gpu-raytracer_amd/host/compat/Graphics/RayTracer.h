@@ -80,6 +80,7 @@ private:
     void mirrorTables();                 // host-layer tables -> the vectors / storages the getters expose
 
     std::unique_ptr<okh::RayTracer> m_impl;
+    std::shared_ptr<okay_compat::PixelSource> m_pixels;  // the link the target texture reads its pixels through
     std::unique_ptr<okh::ResourceManager> m_resources;
     std::unique_ptr<okh::Scene> m_scene;
     const Scene* m_pScene;

@@ -3,6 +3,7 @@
 // types over the okrt C ABI. Not a Direct3D implementation: there is no device, no context, no swap chain.
 #pragma once
 #include <cstdint>
+#include <memory>
 
 #include "okrt.h"
 
@@ -22,11 +23,19 @@ struct D3D11_TEXTURE2D_DESC {
     UINT BindFlags = 0;
 };
 
+// Where a texture's pixels live once a RayTracer renders into it. Shared by the texture and that RayTracer, so either
+// may be destroyed first: the RayTracer clears the link it holds, never reaching through a texture pointer.
+namespace okay_compat {
+struct PixelSource {
+    const okrt_api* api = nullptr;
+    okrt_ctx* ctx = nullptr;
+};
+}  // namespace okay_compat
+
 // A 2D texture = its description + (once a RayTracer renders into it) the okrt context that holds the pixels.
 struct ID3D11Texture2D {
     D3D11_TEXTURE2D_DESC desc;
-    const okrt_api* api = nullptr;
-    okrt_ctx* ctx = nullptr;
+    std::shared_ptr<okay_compat::PixelSource> pixels;
     void GetDesc(D3D11_TEXTURE2D_DESC* out) const { *out = desc; }
 };
 // Views are handles only: the compute path binds tables by okrt slot, not by view.

@@ -441,8 +441,14 @@ bool RayTracer::createOctTree(const Scene& scene, uint32_t maxDepth, uint32_t ma
                 }
             if (taken.empty() || taken.size() == population) continue;
 
+            // every claimed item takes ONE entry out of the cell: the first one filed under the same ENTITY (:672-682). For
+            // an entity that carries a mesh and a sphere (two items, one id) that is the earlier-filed item, whichever
+            // of the two was claimed — the reference's tables keep that quirk, so this does too
             std::vector<uint32_t>& stay = cells[ci].members;
-            stay.erase(std::remove_if(stay.begin(), stay.end(), [&](uint32_t m) { return std::find(taken.begin(), taken.end(), m) != taken.end(); }), stay.end());
+            for (uint32_t t : taken) {
+                const auto it = std::find_if(stay.begin(), stay.end(), [&](uint32_t m) { return items[m].entity == items[t].entity; });
+                if (it != stay.end()) stay.erase(it);
+            }
             const uint32_t childIdx = (uint32_t)cells.size();
             cells.emplace_back();
             cells[childIdx].members = taken;

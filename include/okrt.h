@@ -18,6 +18,7 @@
  *   ClearUnorderedAccessViewFloat(accum)  RayTracer.h:203-209          okrt_reset_accumulation
  *   Okay::updateBuffer(RenderData) + Dispatch  RayTracer.cpp:491,219-260   okrt_render
  *   Okay::getCPUTextureData         DX11.h:32, DX11.cpp:196-230        okrt_read_result_rgba8
+ *   ImGui::Image(result SRV) + present()  Application.cpp:106-128      okrt_peek_result_rgba8
  *   (no reference counterpart: float accumulation readback)            okrt_read_accum_f32x4
  *   Okay::createShader/reloadShader DX11.h:18-22                       (nothing: kernels are AOT)
  *
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define OKRT_ABI_VERSION 2
+#define OKRT_ABI_VERSION 3
 
 typedef struct okrt_ctx okrt_ctx;
 
@@ -155,7 +156,10 @@ typedef enum okrt_option {
      * pixel and frame, see OKRT_OPT_DEFER; 1080p x 64 frames = 12 GiB). 0 (default) = whatever hipMalloc grants. A launch set that
      * does not fit — by this bound or by the allocator — is split in halves until it does; a single frame is
      * always attempted. */
-    OKRT_OPT_QUEUE_MEMORY_MB = 6
+    OKRT_OPT_QUEUE_MEMORY_MB = 6,
+    /* Test hook: n > 0 = the n-th ray-queue allocation from now on fails as hipMalloc would when memory runs out (so that
+     * the launch-set split on a REAL allocator failure can be tested); 0 = off. Process-wide. */
+    OKRT_OPT_DEBUG_FAIL_ALLOC = 7
 } okrt_option;
 
 #define OKRT_BUILDER_HOST 0
@@ -184,6 +188,9 @@ typedef struct okrt_counters {
 
 /* ---- lifetime --------------------------------------------------------------------------- */
 int okrt_abi_version(void);
+/* Number of GPUs this process can open (IDXGIFactory adapter enumeration has no counterpart in the reference: it takes
+ * the default adapter, DX11.cpp:21-42). A multi-GPU host sizes its rank count from this. */
+okrt_status okrt_device_count(int* out_count);
 okrt_status okrt_create(int device, okrt_ctx** out_ctx);
 okrt_status okrt_destroy(okrt_ctx* ctx);
 const char* okrt_last_error(const okrt_ctx* ctx); /* never NULL; "" when no error; ctx == NULL: why the last okrt_create failed */
@@ -217,6 +224,9 @@ okrt_status okrt_set_tile(okrt_ctx* ctx, uint32_t stripe_rows, uint32_t stripe_i
                           uint32_t stripe_stride);
 /* Number of rows this context owns under the current tile. */
 okrt_status okrt_tile_rows(const okrt_ctx* ctx, uint32_t* out_rows);
+/* The frame size of the last okrt_resize (0 x 0 before it): what the read_* calls size their output by, together with
+ * okrt_tile_rows (ID3D11Texture2D::GetDesc of the target texture in the reference, DX11.cpp:200-203). */
+okrt_status okrt_frame_size(const okrt_ctx* ctx, uint32_t* out_width, uint32_t* out_height);
 /* Render into caller-owned device memory instead (e.g. a torch tensor used by an RCCL gather).
  * accum_dev: rows*W float4, result_dev: rows*W RGBA8; NULL selects the internal buffer.
  * Must be re-bound after okrt_resize / okrt_set_tile. */
@@ -236,6 +246,15 @@ okrt_status okrt_synchronize(okrt_ctx* ctx);
 /* Owned rows only, packed: rows*W*4 bytes / rows*W*4 floats. Row 0 = top of the image. */
 okrt_status okrt_read_result_rgba8(okrt_ctx* ctx, uint8_t* dst);
 okrt_status okrt_read_accum_f32x4(okrt_ctx* ctx, float* dst);
+/* For a host that PRESENTS every frame (the reference shows the result texture through ImGui and calls present() once
+ * per loop iteration, Application.cpp:106-128): the newest RESOLVED picture, without executing deferred frames and
+ * without waiting for launch sets still in flight. okrt_read_result_rgba8 is exact but flushes, which costs a per-frame
+ * caller the per-call latency (1.0 ms instead of 0.58 ms per 1080p frame); a display loop `render(); peek(); present();`
+ * keeps the batched rate and shows a picture that is at most one launch set (OKRT_OPT_DEFER frames, default 16) plus the
+ * set in flight behind the accumulation. *out_frames (optional) = the numAccumulationFrames of the picture (0 = nothing
+ * resolved yet: zeros). From the second call on the library keeps two device-side copies of the result, refreshed at the
+ * end of every launch set (8 bytes per pixel extra), and this call only synchronises its own copy stream. */
+okrt_status okrt_peek_result_rgba8(okrt_ctx* ctx, uint8_t* dst, uint32_t* out_frames);
 /* Restore a float accumulation saved with okrt_read_accum_f32x4 (owned rows, packed): together with the host's
  * numAccumulationFrames this resumes a long progressive render ("checkpoint / resume"; the reference
  * has none). */
@@ -262,7 +281,8 @@ okrt_status okrt_last_render_ms(okrt_ctx* ctx, float* out_ms);
  * gaps). *out_frames = number of frames summed. Synchronises. */
 okrt_status okrt_get_stage_ms(okrt_ctx* ctx, float out_ms[3], uint32_t* out_frames);
 /* The same ring, kernel by kernel: out_ms[k] = device time between event k and k + 1 of a launch set, summed over the
- * launch sets in the ring (those with the same number of intervals as the newest one). For the fast pipeline the
+ * launch sets in the ring that have the newest one's shape (same number of intervals AND the same number of frames, so
+ * *out_frames / *out_launches is the real launch-set size). For the fast pipeline the
  * intervals are, in launch order: 0 = the camera-segment kernel, 1 = (frame-slot accumulation when max_bounces == 0),
  * then per later segment b = 1.. : 2b = traceKernel, 2b + 1 = shadeKernel (+ the frame-slot accumulation after the last);
  * the reference-order traversal has one interval. *out_count = number of intervals (at most `capacity` are written),
@@ -337,9 +357,14 @@ okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* 
  * A communicator of one rank never touches RCCL (the gather is a device-to-device copy). */
 #define OKRT_COMM_ID_BYTES 128
 typedef struct okrt_comm okrt_comm;
+/* Transports. "rccl": the sends / receives above (default). "copy" (okrt_comm_create_all only): the root's stream waits
+ * for each peer's stream and pulls the tile with hipMemcpyPeerAsync — chosen when two contexts share a device (RCCL
+ * refuses two ranks on one GPU; this is how an N-rank split is rehearsed on fewer GPUs) or with
+ * OKRT_MGPU_TRANSPORT=copy in the environment. okrt_comm_transport names the one in use ("single" for one rank). */
+const char* okrt_comm_transport(const okrt_comm* comm);
 okrt_status okrt_comm_unique_id(uint8_t out_id[OKRT_COMM_ID_BYTES]);
 okrt_status okrt_comm_create(okrt_ctx* ctx, const uint8_t id[OKRT_COMM_ID_BYTES], uint32_t rank, uint32_t nranks, okrt_comm** out_comm);
-/* ctxs[r] must live on n distinct devices; out_comms receives n communicators, rank r for ctxs[r]. */
+/* out_comms receives n communicators, rank r for ctxs[r]. Distinct devices -> RCCL; shared devices -> copy transport. */
 okrt_status okrt_comm_create_all(okrt_ctx* const* ctxs, uint32_t n, okrt_comm** out_comms);
 okrt_status okrt_comm_destroy(okrt_comm* comm);
 const char* okrt_comm_last_error(const okrt_comm* comm); /* comm == NULL: why the last create on this thread failed */
@@ -347,8 +372,14 @@ const char* okrt_comm_last_error(const okrt_comm* comm); /* comm == NULL: why th
  * of its rank. On `root`, full_frame_dev (device memory, H * W float4; NULL = a library-owned buffer, read it with
  * okrt_mgpu_read_gathered) receives the whole accumulation, row 0 = top. Asynchronous on each context's stream. */
 okrt_status okrt_mgpu_gather_accum(okrt_ctx* ctx, okrt_comm* comm, uint32_t root, void* full_frame_dev);
-/* The same for n contexts driven by one thread (one RCCL group around all sends and receives). */
+/* The same for n contexts driven by one thread (one RCCL group around all sends and receives). n must be the
+ * communicator's whole rank count (or 1): a subset would post sends without their receive. */
 okrt_status okrt_mgpu_gather_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* comms, uint32_t n, uint32_t root, void* full_frame_dev);
+/* Samples split: every rank renders the WHOLE frame (full-frame tile) for its own block of frame
+ * indices; this sums the float4 accumulations onto `root` (ncclReduce; copy transport: pull + add in rank order) into
+ * full_frame_dev or the library-owned frame (okrt_mgpu_read_gathered). alpha of the sum = total frames. */
+okrt_status okrt_mgpu_reduce_accum(okrt_ctx* ctx, okrt_comm* comm, uint32_t root, void* full_frame_dev);
+okrt_status okrt_mgpu_reduce_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* comms, uint32_t n, uint32_t root, void* full_frame_dev);
 /* Root only: copies the library-owned gathered frame (H * W * 4 floats) to the host; synchronises. */
 okrt_status okrt_mgpu_read_gathered(okrt_ctx* ctx, okrt_comm* comm, float* dst);
 /* The root-side step on its own: `tiles_dev` holds nranks packed tiles, tile r at r * tile_stride_rows rows of W float4
@@ -404,6 +435,13 @@ typedef struct okrt_api {
     okrt_status (*mgpu_gather_accum_all)(okrt_ctx* const*, okrt_comm* const*, uint32_t, uint32_t, void*);
     okrt_status (*mgpu_read_gathered)(okrt_ctx*, okrt_comm*, float*);
     okrt_status (*mgpu_deinterleave)(okrt_ctx*, const void*, uint32_t, uint32_t, uint32_t, void*);
+    /* ABI 3 */
+    okrt_status (*device_count)(int*);
+    const char* (*comm_transport)(const okrt_comm*);
+    okrt_status (*mgpu_reduce_accum)(okrt_ctx*, okrt_comm*, uint32_t, void*);
+    okrt_status (*mgpu_reduce_accum_all)(okrt_ctx* const*, okrt_comm* const*, uint32_t, uint32_t, void*);
+    okrt_status (*peek_result_rgba8)(okrt_ctx*, uint8_t*, uint32_t*);
+    okrt_status (*frame_size)(const okrt_ctx*, uint32_t*, uint32_t*);
 } okrt_api;
 
 const okrt_api* okrt_get_api(void);

@@ -76,3 +76,99 @@ def test_deinterleave_rebuilds_the_frame_from_rank_tiles(hip, world, stripe):
     assert np.array_equal(tiling.deinterleave(list(tiles), H, stripe), full, equal_nan=True)  # the Python twin bench.py uses
     assert fns.mgpu_deinterleave(rt.ctx.h, d_tiles, world, stripe, 1, d_full) == -1 or pad == 1  # stride too small is refused
     rt.close()
+
+
+def _split_contexts(desc, W, H, world, stripe, whole_frame=False):
+    rts = []
+    for r in range(world):
+        rt, sc, res = scenes.instantiate(desc, W, H)  # every rank on device 0: the rehearsal layout
+        if not whole_frame:
+            rt.ctx.set_tile(stripe, r, world)
+        rts.append((rt, sc, res))
+    return rts
+
+
+@pytest.mark.parametrize("world,stripe,H", [(2, 8, 54), (3, 5, 37), (8, 8, 135), (3, 8, 16)])
+def test_n_contexts_in_one_process_gather_through_the_copy_transport(world, stripe, H):
+    """What `python bench.py --gpus N` does on a box with fewer GPUs: N contexts in one process, rank r owning stripes
+    r, r+N, ... (okrt_set_tile), joined by okrt_comm_create_all — contexts that share a device get the copy transport —
+    and okrt_mgpu_gather_accum_all: the gathered frame is BIT-identical to one context's full frame. (3, 8, 16): the third
+    rank owns ZERO rows and must still be a valid member of the collective."""
+    desc = scenes.small_mesh_scene(seed=11, n_objects=4, detail=6, with_lights=True)
+    W, FRAMES = 96, 5
+    ref, _, _ = scenes.instantiate(desc, W, H)
+    ref.renderFrames(FRAMES)
+    want = ref.ctx.read_accum().copy()
+    ref.close()
+    rts = _split_contexts(desc, W, H, world, stripe)
+    fns = rts[0][0].ctx.fns
+    ctxs = (P * world)(*[rt.ctx.h for rt, _, _ in rts])
+    comms = (P * world)()
+    assert fns.comm_create_all(ctxs, world, comms) == 0, fns.comm_last_error(None)
+    assert fns.comm_transport(comms[0]) == b"copy"
+    assert sum(rt.ctx.tile_rows() for rt, _, _ in rts) == H
+    for rnd in range(2):  # twice: the peers' streams wait for the root's copy before they render on
+        for rt, _, _ in rts:
+            rt.renderFrames(FRAMES if rnd == 0 else 2)
+        assert fns.mgpu_gather_accum_all(ctxs, comms, world, 0, None) == 0, [fns.last_error(c) for c in ctxs]
+    got = np.zeros((H, W, 4), np.float32)
+    assert fns.mgpu_read_gathered(ctxs[0], comms[0], got.ctypes.data_as(P)) == 0
+    ref, _, _ = scenes.instantiate(desc, W, H)
+    ref.renderFrames(FRAMES + 2)
+    want2 = ref.ctx.read_accum()
+    assert np.array_equal(got, want2, equal_nan=True) and (got[..., 3] == FRAMES + 2).all()
+    assert not np.array_equal(want, want2)
+    ref.close()
+    # a subset of the ranks is refused (its sends would have no receive), and so is a rank passed twice
+    if world > 2:
+        assert fns.mgpu_gather_accum_all(ctxs, comms, world - 1, 0, None) == -1
+    dup_c = (P * world)(*([ctxs[0]] * world))
+    dup_m = (P * world)(*([comms[0]] * world))
+    assert fns.mgpu_gather_accum_all(dup_c, dup_m, world, 0, None) == -1
+    for k in range(world):
+        assert fns.comm_destroy(comms[k]) == 0
+    for rt, _, _ in rts:
+        rt.close()
+
+
+def test_samples_split_reduce_through_the_copy_transport():
+    """bench.py --split samples: every rank renders the WHOLE frame for its own block of frame indices; one reduce sums
+    the accumulations on rank 0 (float order aside it is the accumulation of all the frames)."""
+    desc = scenes.small_mesh_scene(seed=12, n_objects=4, detail=6)
+    W, H, world, per = 80, 45, 3, 4
+    rts = _split_contexts(desc, W, H, world, 8, whole_frame=True)
+    fns = rts[0][0].ctx.fns
+    ctxs = (P * world)(*[rt.ctx.h for rt, _, _ in rts])
+    comms = (P * world)()
+    assert fns.comm_create_all(ctxs, world, comms) == 0, fns.comm_last_error(None)
+    for r, (rt, _, _) in enumerate(rts):
+        rt.render_data.numAccumulationFrames = r * per
+        rt.renderFrames(per)
+    assert fns.mgpu_reduce_accum_all(ctxs, comms, world, 0, None) == 0, [fns.last_error(c) for c in ctxs]
+    got = np.zeros((H, W, 4), np.float32)
+    assert fns.mgpu_read_gathered(ctxs[0], comms[0], got.ctypes.data_as(P)) == 0
+    ref, _, _ = scenes.instantiate(desc, W, H)
+    ref.renderFrames(world * per)
+    want = ref.ctx.read_accum()
+    assert (got[..., 3] == world * per).all() and np.allclose(got, want, rtol=1e-5, atol=1e-6, equal_nan=True)
+    # a tile-split context is refused by the reduce (it needs whole frames)
+    rts[1][0].ctx.set_tile(8, 1, world)
+    assert fns.mgpu_reduce_accum_all(ctxs, comms, world, 0, None) == -4
+    ref.close()
+    for k in range(world):
+        fns.comm_destroy(comms[k])
+    for rt, _, _ in rts:
+        rt.close()
+
+
+def test_device_count_and_frame_size():
+    import ctypes
+    fns = abi.load_device_library()
+    n = ctypes.c_int(0)
+    assert fns.device_count(ctypes.byref(n)) == 0 and n.value >= 1
+    ctx = importlib.import_module("gpu-raytracer_amd.host").Context()
+    assert ctx.frame_size() == (0, 0)
+    ctx.resize(40, 30)
+    ctx.set_tile(8, 1, 2)
+    assert ctx.frame_size() == (40, 30) and ctx.tile_rows() == 14
+    ctx.close()

@@ -323,6 +323,47 @@ def test_launch_sets_shrink_to_the_queue_memory_budget():
     rt.close()
 
 
+def test_launch_sets_shrink_when_the_allocator_says_no():
+    """The same split on a REAL allocator failure (okrt.h, OKRT_OPT_QUEUE_MEMORY_MB: "by this bound or by the allocator"):
+    OKRT_OPT_DEBUG_FAIL_ALLOC makes the n-th queue allocation report hipErrorOutOfMemory. The failed launch set is retried
+    at half the size and must come back OKRT_OK — a stale out-of-memory left behind as HIP's "last error" used to
+    turn the successful retry into OKRT_ERR_DEVICE — with the accumulation bit-identical and every frame counted."""
+    desc = scenes.small_mesh_scene(seed=4, n_objects=5, detail=10, with_lights=True)
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.renderFrames(8)
+    want = rt.ctx.read_accum().copy()
+    rt.close()
+    for nth in (1, 2, 5, 7):  # first queue array, a later one, the hit records, the radiance slots
+        rt, sc, res = scenes.instantiate(desc, 320, 180)
+        rt.ctx.set_option(abi.OPT_TIMING, 8)
+        rt.ctx.set_option(abi.OPT_DEBUG_FAIL_ALLOC, nth)
+        rt.renderFrames(8)  # raises on any status but OKRT_OK
+        got = rt.ctx.read_accum()
+        assert np.array_equal(got, want, equal_nan=True), nth
+        assert rt.getNumAccumulationFrames() == 8 and (got[..., 3] == 8).all()
+        ms, launches, frames = rt.ctx.interval_ms()
+        assert launches == 2 and frames == 8, (nth, launches, frames)  # two sets of four; the refused attempt left no entry behind
+        _, _, _, staged = rt.ctx.stage_ms()
+        assert staged == 8
+        rt.ctx.set_option(abi.OPT_DEBUG_FAIL_ALLOC, 0)
+        rt.close()
+
+
+def test_interval_ms_only_sums_launch_sets_of_the_newest_shape():
+    """okrt_get_interval_ms: 100 frames = 64 + 36; the 36-frame set is the newest, so exactly one launch set of 36 frames
+    is reported (a mixed sum would describe a fictitious 50-frame launch)."""
+    desc = scenes.small_mesh_scene(seed=4, n_objects=4, detail=6)
+    rt, sc, res = scenes.instantiate(desc, 128, 72)
+    rt.ctx.set_option(abi.OPT_TIMING, 16)
+    rt.renderFrames(100)
+    ms, launches, frames = rt.ctx.interval_ms()
+    assert (launches, frames) == (1, 36) and len(ms) == 4 and all(m >= 0 for m in ms)
+    rt.renderFrames(64)
+    ms, launches, frames = rt.ctx.interval_ms()
+    assert (launches, frames) == (2, 128)
+    rt.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_call_sequences_deferred_equals_immediate(seed):
     """API fuzz: the same random sequence of host calls — frames, batched frames, read-backs, option changes, DOF edits,
@@ -373,3 +414,39 @@ def test_random_call_sequences_deferred_equals_immediate(seed):
         else:
             assert x == y
 
+
+
+def test_peek_shows_a_resolved_picture_without_executing_deferred_frames():
+    """okrt_peek_result_rgba8 (the presenting host's read-back, Application.cpp:106-128): the picture it returns is the
+    exact resolve of some earlier frame count — never a torn or half-accumulated one —, asking for it neither executes
+    the deferred frames nor loses them, and the frame count it reports only moves forward."""
+    desc = scenes.small_mesh_scene(seed=6, n_objects=5, detail=8, with_lights=True)
+    W, H = 160, 90
+    # reference pictures: the resolve after exactly k frames, k = 0 .. 40
+    ref, _, _ = scenes.instantiate(desc, W, H)
+    ref.ctx.set_option(abi.OPT_DEFER, 0)
+    pictures = {0: np.zeros((H, W, 4), np.uint8)}
+    for k in range(1, 41):
+        ref.render()
+        pictures[k] = ref.ctx.read_result().copy()
+    ref.close()
+    rt, sc, res = scenes.instantiate(desc, W, H)
+    rt.ctx.set_option(abi.OPT_DEFER, 8)
+    seen = []
+    for k in range(1, 41):
+        rt.render()  # frames wait in groups of 8
+        img, n = rt.ctx.peek_result()
+        assert n <= k and n % 8 == 0 and (not seen or n >= seen[-1]), (k, n, seen[-3:])
+        assert np.array_equal(img, pictures[n]), (k, n)
+        seen.append(n)
+    assert seen[-1] >= 24  # the loop really saw the accumulation progress (not just the initial zeros)
+    assert rt.getNumAccumulationFrames() == 40
+    acc = rt.ctx.read_accum()  # this DOES flush
+    assert (acc[..., 3] == 40).all() and np.array_equal(rt.ctx.read_result(), pictures[40])
+    img, n = rt.ctx.peek_result()
+    assert n == 40 and np.array_equal(img, pictures[40])
+    # a resize drops the stale pictures instead of handing out one of the wrong size
+    rt.onResize(64, 36)
+    img, n = rt.ctx.peek_result()
+    assert img.shape == (36, 64, 4) and n == 0 and not img.any()
+    rt.close()

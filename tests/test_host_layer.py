@@ -282,3 +282,33 @@ def test_hand_built_octree_whole_population_in_one_octant_is_not_split(oracle):
     assert ids[:, [0, 1, 4, 5]].tolist() == [[0, 2, INV, 0]]
     assert np.array_equal(boxes[0], [[0, 0, 0], [3, 3, 3]])
     assert inst_min.tolist() == [[1, 1, 1], [0, 0, 0]]  # Q, P
+
+
+def test_hand_built_octree_entity_with_mesh_and_sphere_is_erased_by_entity_id(oracle):
+    """An entity that carries a mesh AND a sphere is filed twice under one id, and the reference takes a claimed item out
+    of its cell by erasing the FIRST entry with that ENTITY (RayTracer.cpp:672-682), not the claimed entry itself.
+    e0 = cube [-12,12]^3; e1 = cube [-11,11]^3 plus a sphere of radius 0.5 (all at the origin). Mesh view then sphere view,
+    each in reverse creation order: the root files [M1, M0, S1], bounds [-12,12]^3, area 1728. M0 (ratio 1) and M1
+    (1452 / 1728 = 0.84) are too big to move; S1 (box [-0.5,0.5]^3) overlaps octant k=0 (centre (6,-6,6), half 6: distance
+    6 < 6.5) -> cell 1 = [S1] (1 of 3). Erasing by entity removes M1, not S1: the root keeps [M0, S1]. loadOctTree emits a
+    mesh instance for every entry whose ENTITY has a mesh (:736-741), so the table reads e0, e1 (root), e1 (cell 1) —
+    erasing the claimed entry itself would give e1, e0, e1."""
+    res = host.ResourceManager()
+    sc = host.Scene()
+    sc.add_mesh(sc.create_entity(), res.add_mesh(*_cube((0, 0, 0), 12.0)))
+    e1 = sc.create_entity()
+    sc.add_mesh(e1, res.add_mesh(*_cube((0, 0, 0), 11.0)))
+    sc.add_sphere(e1, 0.5)
+    sc.add_camera(sc.create_entity())
+    rt = host.RayTracer(api=oracle.api, fns=oracle.fns)
+    rt.initiate(8, 8, res)
+    rt.setScene(sc)
+    rt.createOctTree(sc, 2, 1)
+    oct_t, inst = rt.table(5), rt.table(7)
+    rt.close()
+    boxes = oct_t[:, :24].copy().view(np.float32).reshape(-1, 2, 3)
+    ids = oct_t[:, 24:].copy().view(np.uint32).reshape(-1, 6)
+    inst_min = inst[:, 136:148].copy().view(np.float32).reshape(-1, 3)
+    assert ids[:, [0, 1, 4, 5]].tolist() == [[0, 2, 1, 1], [2, 3, INV, 0]]
+    assert np.array_equal(boxes[0], [[-12, -12, -12], [12, 12, 12]]) and np.array_equal(boxes[1], [[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]])
+    assert inst_min.tolist() == [[-12, -12, -12], [-11, -11, -11], [-11, -11, -11]]

@@ -1,0 +1,141 @@
+"""The launcher logic of the N-GPU path on CPU (gpu-raytracer_amd/mgpu.py): which process drives which rank, the file
+rendezvous that replaces torch.distributed for a one-process-per-GPU job, and the N-rank tile / samples split through
+the same TileGroup calls bench.py makes — with the oracle standing in for the device and the host-memory transport of
+the rehearsal mode (RCCL needs GPUs; the RCCL leg itself is tests/test_gpu_mgpu.py and the driver's multi-GPU run)."""
+import importlib
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+mgpu = importlib.import_module("gpu-raytracer_amd.mgpu")
+
+
+def test_launch_plan_plain_and_under_a_launcher():
+    lp = mgpu.launch_plan
+    assert lp(1, {}, 1) == dict(mode="single", world=1, rank=0, local_ranks=[0], devices=[0], rehearsal=False)
+    # plain `python bench.py --gpus 8` on an 8-GPU node: one process, rank r on device r
+    p = lp(8, {}, 8)
+    assert p["mode"] == "one_process" and p["world"] == 8 and p["local_ranks"] == list(range(8)) and p["devices"] == list(range(8)) and not p["rehearsal"]
+    # the same command on a 1-GPU box is a rehearsal: every rank on device 0
+    p = lp(2, {}, 1)
+    assert p["mode"] == "one_process" and p["devices"] == [0, 0] and p["rehearsal"]
+    p = lp(4, {}, 2)
+    assert p["devices"] == [0, 1, 0, 1] and p["rehearsal"]
+    # under torch.distributed.run the launcher's world size wins over --gpus, one rank per process
+    env = dict(WORLD_SIZE="4", RANK="2", LOCAL_RANK="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29500")
+    p = lp(1, env, 8)
+    assert p == dict(mode="process_per_gpu", world=4, rank=2, local_ranks=[2], devices=[2], rehearsal=False)
+    p = lp(4, env, 1)
+    assert p["devices"] == [0] and p["rehearsal"]
+    assert lp(4, dict(WORLD_SIZE="1", RANK="0"), 8)["mode"] == "one_process"  # WORLD_SIZE=1 is no launcher at all
+    with pytest.raises(ValueError):
+        lp(1, dict(WORLD_SIZE="2", RANK="5"), 2)
+    # before the GPU count is known the plan already names mode and world (nothing touches a GPU to decide them)
+    assert lp(8, {}, None)["mode"] == "one_process" and lp(8, {}, None)["world"] == 8
+
+
+def _store_rank(rank, world, key, root, out):
+    sys.path.insert(0, REPO)
+    m = importlib.import_module("gpu-raytracer_amd.mgpu")
+    st = m.FileStore(rank, world, key=key, root=root, timeout=60)
+    got = st.allgather(bytes([rank]) * (rank + 1))
+    if rank == 0:
+        st.set("blob", b"x" * 128)
+    blob = st.get("blob")
+    st.barrier()
+    total = m.allreduce_json(st, {"n": rank + 1}, lambda ds: sum(d["n"] for d in ds))
+    st.close()
+    out.put((rank, [len(g) for g in got], [g[:1] for g in got], len(blob), total))
+
+
+def test_file_store_allgather_barrier_close(tmp_path):
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_store_rank, args=(r, world, "t_%d" % os.getpid(), str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, lens, firsts, blob, total in res:
+        assert lens == [1, 2, 3] and firsts == [b"\x00", b"\x01", b"\x02"] and blob == 128 and total == 6
+    assert not [d for d in os.listdir(tmp_path) if d.startswith("okrt_rdzv_")]  # rank 0 removed the directory
+
+
+def _tile_rank(rank, world, key, root, out_path):
+    """What bench.py does per rank in process_per_gpu mode, with the oracle as the device and the host-memory transport."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import conftest
+    m = importlib.import_module("gpu-raytracer_amd.mgpu")
+    env = dict(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    plan = m.launch_plan(1, env, 1)  # one "GPU" for `world` ranks: the rehearsal plan
+    assert plan["rehearsal"] and plan["mode"] == "process_per_gpu"
+    store = m.FileStore(rank, world, key=key, root=root, timeout=120)
+    oracle = conftest.Oracle()
+    oracle.lib.okrt_oracle_set_threads.argtypes = [conftest.C.c_void_p, conftest.C.c_int]
+    desc = conftest.scenes.small_mesh_scene(seed=2, n_objects=4, detail=5, with_lights=True)
+    W, H, SR, FRAMES = 48, 27, 4, 3
+    rt, sc, res = oracle.instantiate(desc, W, H)
+    oracle.lib.okrt_oracle_set_threads(rt.ctx.h, 1)
+    rt.ctx.set_tile(SR, rank, world)
+    group = m.TileGroup(oracle.fns, plan, [rt.ctx.h], store, frame=(W, H, SR), read_tile=lambda k: rt.ctx.read_accum())
+    assert group.host_only and "REHEARSAL" in group.transport
+    rt.renderFrames(FRAMES)
+    group.gather()
+    full = group.read_full()
+    # samples split: whole frame, rank r renders frame indices 2r+1, 2r+2, one sum at the end
+    rt.ctx.set_tile(H, 0, 1)
+    rt.resetAccumulation()
+    rt.render_data.numAccumulationFrames = rank * 2
+    rt.renderFrames(2)
+    group.reduce()
+    summed = group.read_full()
+    if rank == 0:
+        ref_rt, _, _ = oracle.instantiate(desc, W, H)
+        ref_rt.renderFrames(FRAMES)
+        ref = ref_rt.ctx.read_accum()
+        ref_rt.resetAccumulation()
+        ref_rt.renderFrames(2 * world)
+        ref_sum = ref_rt.ctx.read_accum()
+        ok_tiles = np.array_equal(full, ref, equal_nan=True) and bool((full[..., 3] == FRAMES).all())
+        ok_samples = np.allclose(summed, ref_sum, rtol=1e-5, atol=1e-6, equal_nan=True) and bool((summed[..., 3] == 2 * world).all())
+        np.save(out_path, np.array([float(ok_tiles), float(ok_samples)]))
+    else:
+        assert full is None and summed is None
+    group.close()
+    store.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_and_samples_split_through_the_file_store(tmp_path, world):
+    """world processes, no torch: the union of the ranks' tiles is BIT-identical to the full frame; the samples split
+    sums to the same accumulation (float order aside)."""
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "ok.npy")
+    procs = [ctx.Process(target=_tile_rank, args=(r, world, "tile_%d" % os.getpid(), str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok = np.load(out)
+    assert ok[0] == 1.0 and ok[1] == 1.0, ok
+
+
+def test_bench_without_a_gpu_fails_loudly_not_silently():
+    """No GPU in this container: bench.py (any --gpus) must stop at the device count with a clear message — the product
+    has no CPU path — and must not get as far as importing torch or building a scene."""
+    for gpus in ("1", "2"):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=120)
+        if r.returncode == 0:
+            pytest.skip("a GPU is visible here: the loud-failure path cannot be exercised")
+        assert "no GPU visible" in r.stderr and "torch" not in r.stderr, r.stderr[-400:]
