@@ -465,9 +465,11 @@ def main():
             done += min(fpl, 1024 - done)
         ctx.synchronize()
         spp1024_ms = (time.perf_counter() - t1) * 1e3 / 1024
-        t1 = time.perf_counter()
-        img = ctx.read_result()  # the resolve is part of every launch set; this is the copy of the RGBA8 result to the host
-        readback_ms = (time.perf_counter() - t1) * 1e3
+        readback_ms = 1e9
+        for _ in range(3):  # (the first call pays the first touch of its destination pages; a display loop pays the steady cost)
+            t1 = time.perf_counter()
+            img = ctx.read_result()  # the resolve is part of every launch set; this is the copy of the RGBA8 result to the host
+            readback_ms = min(readback_ms, (time.perf_counter() - t1) * 1e3)
         assert img.shape == (H, W, 4)
 
     # ---- job-wide sums and maxima (one_process: all ranks are local) -----------------------------

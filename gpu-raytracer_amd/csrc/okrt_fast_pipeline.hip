@@ -47,13 +47,18 @@ namespace {
 // OKRT_OPT_DEBUG_FAIL_ALLOC: the n-th queue allocation from now on fails as the allocator would (test hook for the
 // launch-set split; 0 = off)
 int g_failAllocIn = 0;
+bool g_failArmed = false;  // only the allocations of a launch set count (launchFast arms it), not the structure build
+struct FailAllocScope {
+    FailAllocScope() { g_failArmed = true; }
+    ~FailAllocScope() { g_failArmed = false; }
+};
 
 template <class T>
 bool devAlloc(T** p, size_t n, std::string& err) {
     if (*p) hipFree(*p);
     *p = nullptr;
     if (!n) return true;
-    hipError_t e = (g_failAllocIn > 0 && --g_failAllocIn == 0) ? hipErrorOutOfMemory : hipMalloc((void**)p, n * sizeof(T));
+    hipError_t e = (g_failArmed && g_failAllocIn > 0 && --g_failAllocIn == 0) ? hipErrorOutOfMemory : hipMalloc((void**)p, n * sizeof(T));
     if (e != hipSuccess) {
         // a failed hipMalloc stays behind as the thread's "last error": taken out here, or the hipGetLastError() after the
         // NEXT (successful, smaller) launch set would report this one
@@ -229,6 +234,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         err = "frames per launch out of range";
         return LaunchStatus::Invalid;
     }
+    const FailAllocScope failScope;
     hipError_t he = hipSuccess;
     auto hipFailed = [&](hipError_t e, const char* what) {
         if (e == hipSuccess) return false;
