@@ -60,6 +60,10 @@ constexpr int kLdsStack = OKRT_LDS_STACK;  // entries per lane kept in LDS
 #ifndef OKRT_TRI_MIN
 #define OKRT_TRI_MIN 24
 #endif
+#ifndef OKRT_DUAL_TRI_MIN
+#define OKRT_DUAL_TRI_MIN 40
+#endif
+constexpr uint32_t kDualTriMin = OKRT_DUAL_TRI_MIN;  // traceDualKernel: the triangle block runs once this many lanes hold a parked leaf
 constexpr int kRefillBelow = OKRT_REFILL_BELOW;  // refill idle lanes when fewer than this many lanes are active
 constexpr uint32_t kNodeMin = OKRT_NODE_MIN, kTriMin = OKRT_TRI_MIN;  // a step block runs when at least this many lanes want it
 constexpr uint32_t kDone = kEmptyRef;

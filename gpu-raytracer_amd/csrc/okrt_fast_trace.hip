@@ -2,6 +2,8 @@
 //   traceKernel         per-ray, persistent, "if-if" scheduling: every segment but the camera one
 //   tracePacketKernel   one wave per 8x8 pixel tile; FUSED = the whole camera segment (generate, trace, shade, append)
 //   fastKatKernel       one thread per ray, the known-answer probe
+#include <cstdlib>
+
 #include "okrt_fast_internal.h"
 
 namespace okrt {
@@ -360,6 +362,255 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         }
     }
 #endif
+}
+
+// ---- per-ray traversal, two work slots per lane ("dual") -------------------------------------------------------------
+// traceKernel above gives a lane ONE unit of work per iteration — a node visit or a triangle test — and runs both step
+// blocks whenever enough lanes want each: a lane whose ray reached a leaf waits for the triangle block while the node
+// block runs half empty, and the other way round (VALU lane utilisation 0.56). Here a lane holds up to TWO pending
+// units, a node reference in `cur` and a leaf in `leaf`: a ray that reaches a leaf parks it and goes on down the tree
+// with whatever its stack holds next, so nearly every live lane can join whichever block the wave decides to run, and
+// the wave runs ONE block per iteration, the one with more takers. The parked leaf is tested a few iterations later than
+// depth-first order would; until then `best` is not yet tightened by it, which costs a few speculative node visits
+// (Aila & Laine's "speculative traversal", here without leaving the one-step-per-iteration loop). The closest hit is
+// the same: every candidate is still tested, nearer wins.
+template <bool COUNT>
+__global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceDualKernel(
+    FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q, HitBuffer hb, ShardView sv, uint32_t cameraFrames, unsigned long long* counters,
+    unsigned long long* rayTotals) {
+    __shared__ uint2 sStack[kLdsStack + 1][kTraceThreads];  // (ref, entry distance), [entry][thread]; row kLdsStack = dummy for predicated-off pushes
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    uint2* myOverflow = fv.overflow + (size_t)(blockIdx.x * kTraceThreads + tid) * fv.overflowCap;
+    if (!COUNT && blockIdx.x == 0 && tid == 0) {  // rays of this launch, always counted (okrt_counters.pixels / .segments)
+        unsigned long long n = 0;
+        if (cameraFrames) n = (unsigned long long)tile.W * tile.rows * cameraFrames;
+        else for (uint32_t k = 0; k < kShards; ++k) n += sv.count(k);
+        if (cameraFrames) atomicAdd(&rayTotals[0], n);
+        atomicAdd(&rayTotals[1], n);
+    }
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t shard = sv.xcdAffinity ? (xcc & (kShards - 1)) : 0u, tried = 0, resNext = 0, resEnd = 0;
+    uint32_t preRaw = 0, preShard = 0;  // prefetched reservation: preRaw is only meaningful in lane 0
+    bool havePre = false;
+
+    uint32_t rayIdx = kInvalid;   // the ray this lane is tracing
+    uint32_t cur = kDone;         // node (or, while the leaf slot is taken, a second leaf) to process next; kDone = none
+    uint32_t leaf = kDone;        // parked leaf, kDone = none
+    uint32_t triJ = 0;            // the triangle of `leaf` to test next
+    uint32_t sp = 0;
+    V3 ro = mk(0, 0, 0), rdir = mk(0, 0, 0), iq = mk(0, 0, 0);
+    float best = kFltMax, hbu = 0.f, hbv = 0.f;
+    uint32_t hitIdx = kInvalid, hitTri = kInvalid;
+    uint32_t nNodes = 0, nTris = 0, nSeg = 0;
+    bool exhausted = false;
+
+    // next stack entry the current best does not already beat
+    auto popNext = [&]() -> uint32_t {
+        while (sp > 0) {
+            --sp;
+            uint2 e;
+            if (sp < (uint32_t)kLdsStack) e = sStack[sp][tid];  // (kept apart from the spill slab: one ds_read_b64, not a flat load)
+            else e = myOverflow[sp - kLdsStack];
+            if (__uint_as_float(e.y) < best) return e.x;
+        }
+        return kDone;
+    };
+    // a leaf reference waiting in `cur` moves into the free leaf slot and the traversal goes on with the next entry
+    auto parkLeaf = [&]() {
+        if ((int)cur < -1 && leaf == kDone) {  // bit 31 set and not kDone
+            leaf = cur;
+            triJ = 0;
+            cur = popNext();
+        }
+    };
+    for (;;) {
+        // ---- refill: lanes whose traversal ended store their hit and take the next rays --------
+        const unsigned long long idle = __ballot(cur == kDone && leaf == kDone);
+        if ((uint32_t)__popcll(~idle) < (uint32_t)kRefillBelow) {
+            if (cur == kDone && leaf == kDone && rayIdx != kInvalid) {
+                stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
+                stStream(&hb.tri[rayIdx], hitTri);
+                rayIdx = kInvalid;
+            }
+            for (int round = 0; round < 2 && !exhausted; ++round) {
+                const unsigned long long need = __ballot(rayIdx == kInvalid);
+                if (!need) break;
+                if (resNext == resEnd) {  // take the prefetched reservation (wave-uniform); steal when a shard is dry
+                    while (tried < kShards) {
+                        if (!havePre) {
+                            if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], sv.batch ? sv.batch : (uint32_t)__popcll(need));
+                            preShard = shard;
+                            havePre = true;
+                        }
+                        const uint32_t bpos = __builtin_amdgcn_readfirstlane(preRaw);  // waits for the atomic here
+                        const uint32_t cnt = sv.count(preShard);
+                        havePre = false;
+                        if (bpos < cnt) {
+                            resNext = preShard * sv.cap + bpos;
+                            resEnd = preShard * sv.cap + min(bpos + (sv.batch ? sv.batch : (uint32_t)__popcll(need)), cnt);
+                            tried = 0;
+                            break;
+                        }
+                        // this shard is dry: look at all cursors with ONE load (lane k reads shard k) and jump to the
+                        // next shard that still has rays, instead of probing each with a returning atomic
+                        uint32_t seen = 0xFFFFFFFFu, lim = 0;
+                        if (lane < kShards) {
+                            seen = __hip_atomic_load(&sv.cursors[lane * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            lim = sv.count(lane);
+                        }
+                        const uint32_t live = (uint32_t)__ballot(seen < lim) & ((1u << kShards) - 1u);
+                        if (!live) {
+                            tried = kShards;
+                            break;
+                        }
+                        const uint32_t rot = ((live >> shard) | (live << (kShards - shard))) & ((1u << kShards) - 1u);  // bit j = shard+j
+                        shard = (shard + (uint32_t)__builtin_ctz(rot)) & (kShards - 1);
+                        tried++;
+                    }
+                    if (resNext == resEnd) {
+                        exhausted = true;
+                        break;
+                    }
+                    if (sv.batch) {  // issue the NEXT reservation now; its round trip overlaps the traversal of this batch
+                        if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], sv.batch);
+                        preShard = shard;
+                        havePre = true;
+                    }
+                }
+                const uint32_t avail = resEnd - resNext;
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (rayIdx == kInvalid && rank < avail) {
+                    const uint32_t mine = resNext + rank;
+                    const float4 A = ldStream(&q.a[mine]), B = ldStream(&q.b[mine]);
+                    Ray ray;
+                    ray.origin = mk(A.x, A.y, A.z);
+                    ray.direction = mk(A.w, B.x, B.y);
+                    if (__float_as_uint(B.w) != kInvalid) {  // camera-ray padding outside the image carries pix = kInvalid
+                        rayIdx = mine;
+                        nSeg++;
+                        ro = ray.origin;
+                        rdir = normalize(ray.direction);  // the shader re-normalises the direction per instance (RaytracerCS.hlsl:276)
+                        iq = rcp3(rdir);  // clamped to +-1e30 so that 0 * inf cannot poison the fused slab arithmetic
+                        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
+                        best = kFltMax;
+                        hitIdx = kInvalid;
+                        hitTri = kInvalid;
+                        hbu = hbv = 0.f;
+                        for (uint32_t i = 0; i < rd.numSpheres; i++) {  // RaytracerCS.hlsl:232-242 (original direction)
+                            float d = rayAndSphere(ray, ld3(s.spheres[i].position), s.spheres[i].radius);
+                            if (d > 0.f && d < best) {
+                                best = d;
+                                hitIdx = i;
+                            }
+                        }
+                        sp = 0;
+                        cur = 0;  // root node
+                        leaf = kDone;
+                    }
+                }
+                resNext += min((uint32_t)__popcll(need), avail);
+            }
+            if (__ballot(rayIdx != kInvalid) == 0ull) break;  // queues drained and every lane idle
+        }
+
+        // ---- ONE block per iteration, the one more lanes can join ------------------------------------------------------
+        const bool hasNode = (int)cur >= 0, hasLeaf = leaf != kDone;
+        const uint32_t wantNode = (uint32_t)__popcll(__ballot(hasNode)), wantTri = (uint32_t)__popcll(__ballot(hasLeaf));
+        // triangles when enough leaves are parked, or when they outnumber the nodes (lanes blocked on a second leaf count twice)
+        const bool runTri = wantTri >= kDualTriMin || wantTri > wantNode;
+        if (!runTri) {
+            if (hasNode) {
+                const uint4* p = fv.nodes + (size_t)cur * 4;
+                const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
+                if (COUNT) nNodes++;
+                float tn[4];
+                uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
+                // slab test on the node's grid: t = (origin + q*step - o)/d = fma(q, step/d, (origin - o)/d)
+                const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
+                const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
+                const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
+                // entry planes are the lower ones for a positive direction component, the upper ones otherwise
+                const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
+                const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
+                const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
+                                              fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
+                    const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
+                                             fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
+                    const bool hit = tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef;
+                    tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
+                }
+                // sort the four (distance, child) pairs ascending: 5-comparator network, select-based (no branches)
+#define OKRT_CSWAP(i, j)                                              \
+    {                                                                 \
+        const bool sw_ = tn[j] < tn[i];                               \
+        const float lo_ = sw_ ? tn[j] : tn[i], hi_ = sw_ ? tn[i] : tn[j];     \
+        const uint32_t cl_ = sw_ ? ch[j] : ch[i], chh_ = sw_ ? ch[i] : ch[j]; \
+        tn[i] = lo_; tn[j] = hi_; ch[i] = cl_; ch[j] = chh_;          \
+    }
+                OKRT_CSWAP(0, 1) OKRT_CSWAP(2, 3) OKRT_CSWAP(0, 2) OKRT_CSWAP(1, 3) OKRT_CSWAP(1, 2)
+#undef OKRT_CSWAP
+                // hits are now ch[0..n-1]; push n-1 far ones so that ch[1] ends on top, continue with ch[0]
+                const uint32_t n = (tn[0] < kFltMax) + (tn[1] < kFltMax) + (tn[2] < kFltMax) + (tn[3] < kFltMax);
+                if (sp + 3 <= (uint32_t)kLdsStack) {  // fast path: three unconditional 8-byte LDS writes, misses go to the dummy row
+                    const uint32_t top = sp + n;      // entry k (1..n-1) lands at sp + n-1-k
+                    sStack[1 < n ? top - 2 : kLdsStack][tid] = make_uint2(ch[1], __float_as_uint(tn[1]));
+                    sStack[2 < n ? top - 3 : kLdsStack][tid] = make_uint2(ch[2], __float_as_uint(tn[2]));
+                    sStack[3 < n ? top - 4 : kLdsStack][tid] = make_uint2(ch[3], __float_as_uint(tn[3]));
+                    sp += n > 1 ? n - 1 : 0;
+                } else {  // deep in the tree: spill to the per-thread HBM slab
+#pragma unroll
+                    for (int k = 3; k >= 1; --k) {
+                        if (tn[k] < kFltMax) {
+                            if (sp < (uint32_t)kLdsStack) sStack[sp][tid] = make_uint2(ch[k], __float_as_uint(tn[k]));
+                            else if (sp - kLdsStack < fv.overflowCap) myOverflow[sp - kLdsStack] = make_uint2(ch[k], __float_as_uint(tn[k]));
+                            else continue;  // cannot happen: the slab is sized from the tree depth
+                            sp++;
+                        }
+                    }
+                }
+                cur = n ? ch[0] : popNext();
+                parkLeaf();
+            }
+        } else if (hasLeaf) {  // Moeller-Trumbore on triangle triJ of the parked leaf
+            const uint4* p = (const uint4*)fv.tris + (size_t)((leaf & 0x07FFFFFFu) + triJ) * 3;
+            const uint4 d0 = p[0], d1 = p[1], d2 = p[2];
+            if (COUNT) nTris++;
+            float bu = 0.f, bv = 0.f;
+            const float t = rayAndTriangleEdges(ro, rdir, mk(__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)),
+                                                mk(__uint_as_float(d1.x), __uint_as_float(d1.y), __uint_as_float(d1.z)),
+                                                mk(__uint_as_float(d2.x), __uint_as_float(d2.y), __uint_as_float(d2.z)), bu, bv);
+            if (t > 0.f) {
+                const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314 with M = identity (world-space triangles)
+                if (d < best) {  // nearer wins (:316, strict)
+                    best = d;
+                    hbu = bu;
+                    hbv = bv;
+                    hitTri = d0.w;
+                    hitIdx = d1.w;
+                }
+            }
+            if (++triJ > ((leaf >> 27) & 15u)) {  // count - 1 is stored
+                leaf = kDone;
+                // what the stack held may be beaten now: a node in `cur` is re-checked when visited (its children fail
+                // tnear < best); a second leaf waiting in `cur` moves up
+                parkLeaf();
+            }
+        }
+    }
+    if (COUNT && counters) {
+        uint32_t vals[3] = {nSeg, nNodes, nTris};
+        const int slot[3] = {1, 10, 11};  // segments, fast_nodes, fast_tris
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint32_t v = vals[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
+        }
+    }
 }
 
 // ---- packet traversal of camera rays --------------------------------------------------------------------------------
@@ -862,6 +1113,12 @@ void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, 
                  RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals,
                  const TailView& tv) {
     const dim3 tb(kTraceThreads);
+    static const bool dual = !getenv("OKRT_FAST_DUAL") || atoi(getenv("OKRT_FAST_DUAL")) != 0;
+    if (dual && !tv.ctr) {
+        if (count) hipLaunchKernelGGL((traceDualKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+        else hipLaunchKernelGGL((traceDualKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+        return;
+    }
     if (count) hipLaunchKernelGGL((traceKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, tv);
     else hipLaunchKernelGGL((traceKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, tv);
 }
