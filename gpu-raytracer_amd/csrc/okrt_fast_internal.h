@@ -63,6 +63,13 @@ constexpr int kLdsStack = OKRT_LDS_STACK;  // entries per lane kept in LDS
 #ifndef OKRT_DUAL_TRI_MIN
 #define OKRT_DUAL_TRI_MIN 40
 #endif
+#ifndef OKRT_DUAL_SPECULATE
+#define OKRT_DUAL_SPECULATE 0
+#endif
+#ifndef OKRT_DUAL_POLICY
+#define OKRT_DUAL_POLICY 2  // which step blocks an iteration runs: 0 = lane-count thresholds, 1 = work retired per instruction issued, 2 = one block, triangles from kDualTriMin lanes
+#endif
+constexpr uint32_t kHold = 0xFFFFFFFEu;  // traceDualKernel without speculation: "pop the stack when the parked leaf is done"
 constexpr uint32_t kDualTriMin = OKRT_DUAL_TRI_MIN;  // traceDualKernel: the triangle block runs once this many lanes hold a parked leaf
 constexpr int kRefillBelow = OKRT_REFILL_BELOW;  // refill idle lanes when fewer than this many lanes are active
 constexpr uint32_t kNodeMin = OKRT_NODE_MIN, kTriMin = OKRT_TRI_MIN;  // a step block runs when at least this many lanes want it

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
     uint32_t hitIdx = kInvalid, hitTri = kInvalid;
     uint32_t nNodes = 0, nTris = 0, nSeg = 0;
     bool exhausted = false;
+#ifdef OKRT_STAMPS_BLOCKS  // diagnostic build: wave-level executions of the two step blocks and the lanes that took part (tools/stamps2.py)
+    unsigned long long stNodeWave = 0, stNodeLane = 0, stTriWave = 0, stTriLane = 0, stIter = 0, stLive = 0;
+#endif
 #if OKRT_TAIL_DRAIN
     uint32_t tailIter = 0;        // iterations since this wave ran out of work (wave-uniform)
     bool tailOpen = tv.ctr != nullptr;
@@ -226,6 +229,12 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             runTri = !runNode && wantTri;
         }
         const bool stepNode = isNode && runNode, stepTri = isTri && runTri;
+#ifdef OKRT_STAMPS_BLOCKS
+        stIter++;
+        stLive += __popcll(__ballot(cur != kDone));
+        if (runNode) { stNodeWave++; stNodeLane += wantNode; }
+        if (runTri) { stTriWave++; stTriLane += wantTri; }
+#endif
         uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, d2 = d0, d3 = d0;
         if (stepNode || stepTri) {
             const uint4* p = stepNode ? fv.nodes + (size_t)cur * 4 : (const uint4*)fv.tris + (size_t)((cur & 0x07FFFFFFu) + triJ) * 3;
@@ -350,6 +359,13 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         atomicAdd(&counters[6], nodeWave); atomicAdd(&counters[7], nodeLane); atomicAdd(&counters[8], leafWave); atomicAdd(&counters[9], leafLane);
     }
 #endif
+#ifdef OKRT_STAMPS_BLOCKS
+    if (COUNT && counters && lane == 0) {
+        atomicAdd(&counters[0], stLive);
+        atomicAdd(&counters[1], stIter << 32);  // (iterations ride in the high half of `segments`)
+        atomicAdd(&counters[2], stNodeWave); atomicAdd(&counters[3], stNodeLane); atomicAdd(&counters[4], stTriWave); atomicAdd(&counters[5], stTriLane);
+    }
+#endif
 #ifndef OKRT_ITER_HIST
     if (COUNT && counters) {
         uint32_t vals[3] = {nSeg, nNodes, nTris};
@@ -404,6 +420,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
     uint32_t hitIdx = kInvalid, hitTri = kInvalid;
     uint32_t nNodes = 0, nTris = 0, nSeg = 0;
     bool exhausted = false;
+#ifdef OKRT_STAMPS_BLOCKS  // diagnostic build: wave-level executions of the two step blocks and the lanes that took part (tools/stamps2.py)
+    unsigned long long stNodeWave = 0, stNodeLane = 0, stTriWave = 0, stTriLane = 0, stIter = 0, stRefill = 0, stLive = 0;
+#endif
 
     // next stack entry the current best does not already beat
     auto popNext = [&]() -> uint32_t {
@@ -421,13 +440,20 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         if ((int)cur < -1 && leaf == kDone) {  // bit 31 set and not kDone
             leaf = cur;
             triJ = 0;
+#if OKRT_DUAL_SPECULATE
             cur = popNext();
+#else
+            cur = kHold;  // depth-first order kept: the stack is popped once this leaf has been tested
+#endif
         }
     };
     for (;;) {
         // ---- refill: lanes whose traversal ended store their hit and take the next rays --------
         const unsigned long long idle = __ballot(cur == kDone && leaf == kDone);
         if ((uint32_t)__popcll(~idle) < (uint32_t)kRefillBelow) {
+#ifdef OKRT_STAMPS_BLOCKS
+            stRefill++;
+#endif
             if (cur == kDone && leaf == kDone && rayIdx != kInvalid) {
                 stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
                 stStream(&hb.tri[rayIdx], hitTri);
@@ -514,36 +540,65 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             if (__ballot(rayIdx != kInvalid) == 0ull) break;  // queues drained and every lane idle
         }
 
-        // ---- ONE block per iteration, the one more lanes can join ------------------------------------------------------
+        // ---- step blocks ----------------------------------------------------------------------------------------------
+        // A block runs when at least kNodeMin / kTriMin lanes want it (both may run in one iteration: one wait for both
+        // sets of loads); when neither has that many takers the bigger group runs, the other lanes wait a round and
+        // join a fuller block. All loads of the iteration are issued together, through one pointer per lane.
         const bool hasNode = (int)cur >= 0, hasLeaf = leaf != kDone;
         const uint32_t wantNode = (uint32_t)__popcll(__ballot(hasNode)), wantTri = (uint32_t)__popcll(__ballot(hasLeaf));
-        // triangles when enough leaves are parked, or when they outnumber the nodes (lanes blocked on a second leaf count twice)
-        const bool runTri = wantTri >= kDualTriMin || wantTri > wantNode;
-        if (!runTri) {
-            if (hasNode) {
-                const uint4* p = fv.nodes + (size_t)cur * 4;
-                const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
-                if (COUNT) nNodes++;
-                float tn[4];
-                uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
-                // slab test on the node's grid: t = (origin + q*step - o)/d = fma(q, step/d, (origin - o)/d)
-                const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
-                const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
-                const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
-                // entry planes are the lower ones for a positive direction component, the upper ones otherwise
-                const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
-                const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
-                const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
+#if OKRT_DUAL_POLICY == 0
+        bool runNode = wantNode >= kNodeMin, runTri = wantTri >= kTriMin;
+        if (!runNode && !runTri) {
+            runNode = wantNode >= wantTri && wantNode;
+            runTri = !runNode && wantTri;
+        }
+#elif OKRT_DUAL_POLICY == 1
+        // the choice that retires the most work per instruction issued THIS iteration: a node visit is worth its ~176 VALU
+        // instructions, a triangle test its ~95, every iteration pays ~40 of bookkeeping on top (x 1024, integers)
+        const uint32_t effNode = 834u * wantNode, effTri = 721u * wantTri, effBoth = 579u * wantNode + 313u * wantTri;
+        const bool runNode = wantNode && (effNode >= effTri || effBoth > effTri);
+        const bool runTri = wantTri && (effTri > effNode || effBoth > effNode);
+#else
+        const bool runTri = wantTri >= kDualTriMin || wantTri > wantNode, runNode = !runTri;
+#endif
+        const bool stepNode = hasNode && runNode, stepTri = hasLeaf && runTri && !stepNode;  // (speculating lanes hold both: the node first)
+#ifdef OKRT_STAMPS_BLOCKS
+        stIter++;
+        stLive += __popcll(__ballot(cur != kDone || leaf != kDone));
+        if (runNode) { stNodeWave++; stNodeLane += __popcll(__ballot(stepNode)); }
+        if (runTri) { stTriWave++; stTriLane += __popcll(__ballot(stepTri)); }
+#endif
+        uint4 d0, d1, d2, d3;
+        if (stepNode || stepTri) {
+            const uint4* p = stepNode ? fv.nodes + (size_t)cur * 4 : (const uint4*)fv.tris + (size_t)((leaf & 0x07FFFFFFu) + triJ) * 3;
+            d0 = p[0];
+            d1 = p[1];
+            d2 = p[2];
+            if (stepNode) d3 = p[3];
+        }
+        if (stepNode) {
+            const uint4 n0 = d0, n1 = d1, n2 = d2, n3 = d3;
+            if (COUNT) nNodes++;
+            float tn[4];
+            uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
+            // slab test on the node's grid: t = (origin + q*step - o)/d = fma(q, step/d, (origin - o)/d)
+            const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
+            const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
+            const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
+            // entry planes are the lower ones for a positive direction component, the upper ones otherwise
+            const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
+            const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
+            const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
-                                              fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
-                    const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
-                                             fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
-                    const bool hit = tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef;
-                    tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
-                }
-                // sort the four (distance, child) pairs ascending: 5-comparator network, select-based (no branches)
+            for (int k = 0; k < 4; ++k) {
+                const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
+                                          fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
+                const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
+                                         fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
+                const bool hit = tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef;
+                tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
+            }
+            // sort the four (distance, child) pairs ascending: 5-comparator network, select-based (no branches)
 #define OKRT_CSWAP(i, j)                                              \
     {                                                                 \
         const bool sw_ = tn[j] < tn[i];                               \
@@ -551,33 +606,31 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         const uint32_t cl_ = sw_ ? ch[j] : ch[i], chh_ = sw_ ? ch[i] : ch[j]; \
         tn[i] = lo_; tn[j] = hi_; ch[i] = cl_; ch[j] = chh_;          \
     }
-                OKRT_CSWAP(0, 1) OKRT_CSWAP(2, 3) OKRT_CSWAP(0, 2) OKRT_CSWAP(1, 3) OKRT_CSWAP(1, 2)
+            OKRT_CSWAP(0, 1) OKRT_CSWAP(2, 3) OKRT_CSWAP(0, 2) OKRT_CSWAP(1, 3) OKRT_CSWAP(1, 2)
 #undef OKRT_CSWAP
-                // hits are now ch[0..n-1]; push n-1 far ones so that ch[1] ends on top, continue with ch[0]
-                const uint32_t n = (tn[0] < kFltMax) + (tn[1] < kFltMax) + (tn[2] < kFltMax) + (tn[3] < kFltMax);
-                if (sp + 3 <= (uint32_t)kLdsStack) {  // fast path: three unconditional 8-byte LDS writes, misses go to the dummy row
-                    const uint32_t top = sp + n;      // entry k (1..n-1) lands at sp + n-1-k
-                    sStack[1 < n ? top - 2 : kLdsStack][tid] = make_uint2(ch[1], __float_as_uint(tn[1]));
-                    sStack[2 < n ? top - 3 : kLdsStack][tid] = make_uint2(ch[2], __float_as_uint(tn[2]));
-                    sStack[3 < n ? top - 4 : kLdsStack][tid] = make_uint2(ch[3], __float_as_uint(tn[3]));
-                    sp += n > 1 ? n - 1 : 0;
-                } else {  // deep in the tree: spill to the per-thread HBM slab
+            // hits are now ch[0..n-1]; push n-1 far ones so that ch[1] ends on top, continue with ch[0]
+            const uint32_t n = (tn[0] < kFltMax) + (tn[1] < kFltMax) + (tn[2] < kFltMax) + (tn[3] < kFltMax);
+            if (sp + 3 <= (uint32_t)kLdsStack) {  // fast path: three unconditional 8-byte LDS writes, misses go to the dummy row
+                const uint32_t top = sp + n;      // entry k (1..n-1) lands at sp + n-1-k
+                sStack[1 < n ? top - 2 : kLdsStack][tid] = make_uint2(ch[1], __float_as_uint(tn[1]));
+                sStack[2 < n ? top - 3 : kLdsStack][tid] = make_uint2(ch[2], __float_as_uint(tn[2]));
+                sStack[3 < n ? top - 4 : kLdsStack][tid] = make_uint2(ch[3], __float_as_uint(tn[3]));
+                sp += n > 1 ? n - 1 : 0;
+            } else {  // deep in the tree: spill to the per-thread HBM slab
 #pragma unroll
-                    for (int k = 3; k >= 1; --k) {
-                        if (tn[k] < kFltMax) {
-                            if (sp < (uint32_t)kLdsStack) sStack[sp][tid] = make_uint2(ch[k], __float_as_uint(tn[k]));
-                            else if (sp - kLdsStack < fv.overflowCap) myOverflow[sp - kLdsStack] = make_uint2(ch[k], __float_as_uint(tn[k]));
-                            else continue;  // cannot happen: the slab is sized from the tree depth
-                            sp++;
-                        }
+                for (int k = 3; k >= 1; --k) {
+                    if (tn[k] < kFltMax) {
+                        if (sp < (uint32_t)kLdsStack) sStack[sp][tid] = make_uint2(ch[k], __float_as_uint(tn[k]));
+                        else if (sp - kLdsStack < fv.overflowCap) myOverflow[sp - kLdsStack] = make_uint2(ch[k], __float_as_uint(tn[k]));
+                        else continue;  // cannot happen: the slab is sized from the tree depth
+                        sp++;
                     }
                 }
-                cur = n ? ch[0] : popNext();
-                parkLeaf();
             }
-        } else if (hasLeaf) {  // Moeller-Trumbore on triangle triJ of the parked leaf
-            const uint4* p = (const uint4*)fv.tris + (size_t)((leaf & 0x07FFFFFFu) + triJ) * 3;
-            const uint4 d0 = p[0], d1 = p[1], d2 = p[2];
+            cur = n ? ch[0] : popNext();
+            parkLeaf();
+        }
+        if (stepTri) {  // Moeller-Trumbore on triangle triJ of the parked leaf
             if (COUNT) nTris++;
             float bu = 0.f, bv = 0.f;
             const float t = rayAndTriangleEdges(ro, rdir, mk(__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)),
@@ -595,12 +648,25 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             }
             if (++triJ > ((leaf >> 27) & 15u)) {  // count - 1 is stored
                 leaf = kDone;
+#if OKRT_DUAL_SPECULATE
                 // what the stack held may be beaten now: a node in `cur` is re-checked when visited (its children fail
                 // tnear < best); a second leaf waiting in `cur` moves up
                 parkLeaf();
+#else
+                cur = popNext();
+                parkLeaf();
+#endif
             }
         }
     }
+#ifdef OKRT_STAMPS_BLOCKS
+    if (COUNT && counters && lane == 0) {  // pixels += iterations; n_oct.. = node block executions, its lanes, triangle block executions, its lanes
+        (void)stRefill; (void)stLive;
+        atomicAdd(&counters[0], stLive);
+        atomicAdd(&counters[1], stIter << 32);  // (iterations ride in the high half of `segments`)
+        atomicAdd(&counters[2], stNodeWave); atomicAdd(&counters[3], stNodeLane); atomicAdd(&counters[4], stTriWave); atomicAdd(&counters[5], stTriLane);
+    }
+#endif
     if (COUNT && counters) {
         uint32_t vals[3] = {nSeg, nNodes, nTris};
         const int slot[3] = {1, 10, 11};  // segments, fast_nodes, fast_tris
