@@ -58,6 +58,13 @@ struct okrt_ctx {
     okrt_render_data pendingRd{};
     bool externalFramebuffers = false, externalStream = false;
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
+    // OKRT_OPT_PIPELINE: consecutive launch sets of a progressive accumulation alternate between two queue slots and two
+    // streams, so the next set's bulk fills the GPU while the previous set's last rays drain. Only the accumulation is
+    // ordered between them (accumDone events). Every entry point but the render calls joins stream B back into `stream`.
+    bool pipelineOn = true, bActive = false, needSyncB = true, accumChain = false;
+    hipStream_t streamB = nullptr;
+    hipEvent_t accumDone[2] = {nullptr, nullptr}, evJoinA = nullptr, evJoinB = nullptr;
+    uint32_t pipeNext = 0, pipeLast = 0;
     // okrt_peek_result_rgba8: two device-side copies of the resolved picture, refreshed alternately at the end of every
     // launch set once a host has asked for one; the peek copies the newest finished one out on its own stream
     bool peekOn = false;
@@ -107,7 +114,25 @@ okrt_status flushPending(okrt_ctx* c) {
     c->pending = 0;
     return renderBatched(c, &c->pendingRd, n, true);
 }
+// Everything launched on stream B so far is ordered before whatever follows on the context's main stream; the next
+// launch on B waits for the main stream in turn (uploads, resets, ... made there).
+okrt_status joinStreams(okrt_ctx* c) {
+    c->needSyncB = true;
+    if (!c->bActive) return OKRT_OK;
+    c->bActive = false;
+    if (hipSetDevice(c->device) != hipSuccess || hipEventRecord(c->evJoinB, c->streamB) != hipSuccess || hipStreamWaitEvent(c->stream, c->evJoinB, 0) != hipSuccess)
+        return fail(c, OKRT_ERR_DEVICE, "pipeline: joining the second stream failed");
+    return OKRT_OK;
+}
+// every entry point that observes or changes state: deferred frames executed, both streams joined
 #define OKRT_FLUSH(c)                                \
+    do {                                             \
+        okrt_status fs_ = flushPending(c);           \
+        if (fs_ == OKRT_OK) fs_ = joinStreams(c);    \
+        if (fs_ != OKRT_OK) return fs_;              \
+    } while (0)
+// the render calls themselves: launch sets may stay in flight on both streams
+#define OKRT_FLUSH_KEEP_PIPELINE(c)                  \
     do {                                             \
         okrt_status fs_ = flushPending(c);           \
         if (fs_ != OKRT_OK) return fs_;              \
@@ -305,6 +330,9 @@ okrt_status okrt_create(int device, okrt_ctx** out) {
     c->stream = c->ownStream;
     hipEventCreate(&c->evBegin);
     hipEventCreate(&c->evEnd);
+    if (hipStreamCreateWithFlags(&c->streamB, hipStreamNonBlocking) != hipSuccess) c->streamB = nullptr, c->pipelineOn = false;
+    for (hipEvent_t* e : {&c->accumDone[0], &c->accumDone[1], &c->evJoinA, &c->evJoinB})
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) c->pipelineOn = false;
     if ((e = hipMalloc(&c->counters.ptr, kNumCounters * sizeof(unsigned long long))) != hipSuccess) {
         g_createError = std::string("hipMalloc: ") + hipGetErrorString(e);
         delete c;
@@ -320,7 +348,14 @@ okrt_status okrt_destroy(okrt_ctx* c) {
     if (!c) return OKRT_ERR_INVALID_ARG;
     (void)flushPending(c);
     hipSetDevice(c->device);
+    (void)joinStreams(c);
     hipStreamSynchronize(c->stream);
+    if (c->streamB) {
+        hipStreamSynchronize(c->streamB);
+        hipStreamDestroy(c->streamB);
+    }
+    for (hipEvent_t e : {c->accumDone[0], c->accumDone[1], c->evJoinA, c->evJoinB})
+        if (e) hipEventDestroy(e);
     for (Table& t : c->tables)
         if (t.dev.ptr) hipFree(t.dev.ptr);
     for (DeviceBuffer* b : {&c->textures, &c->env, &c->shadeInfo, &c->accumOwn, &c->resultOwn, &c->counters, &c->front[0], &c->front[1]})
@@ -532,7 +567,7 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
     const bool defer = c->deferMax > 1 && !c->externalFramebuffers && !c->externalStream && c->traversal == OKRT_TRAVERSAL_FAST &&
                        rd->debugMode == 0 && rd->accumulationEnabled == 1;
     if (!defer) {
-        OKRT_FLUSH(c);
+        OKRT_FLUSH_KEEP_PIPELINE(c);
         return renderImpl(c, rd, 1);
     }
     okrt_status s = checkRenderArgs(c, rd);
@@ -542,7 +577,7 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
     if (c->pending) {
         okrt_render_data expect = c->pendingRd;
         expect.numAccumulationFrames += c->pending;  // the host's pre-increment per frame (RayTracer.cpp:489)
-        if (std::memcmp(&expect, rd, sizeof(expect)) != 0) OKRT_FLUSH(c);
+        if (std::memcmp(&expect, rd, sizeof(expect)) != 0) OKRT_FLUSH_KEEP_PIPELINE(c);
     }
     if (!c->pending) c->pendingRd = *rd;
     if (++c->pending >= c->deferMax) return flushPending(c);
@@ -551,7 +586,7 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
 
 okrt_status okrt_render_frames(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
-    OKRT_FLUSH(c);
+    OKRT_FLUSH_KEEP_PIPELINE(c);
     if (!frames) return OKRT_OK;
     const bool batchable = c->traversal == OKRT_TRAVERSAL_FAST && rd->debugMode == 0 && rd->accumulationEnabled == 1;
     return renderBatched(c, rd, frames, batchable);
@@ -653,21 +688,57 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
         }
     }
     int used = 0;
+    hipStream_t launchStream = c->stream;
+    // Two launch sets in flight: a set that merely continues a progressive accumulation takes the queue slot and stream
+    // the previous set did NOT use, so its camera rays fill the GPU while that set's last bounce rays drain; its one
+    // accumulation kernel waits for the previous set's. Sets of more than kPipelineMaxFrames frames stay on one slot
+    // (two of them would double the largest queue footprint for a fixed cost that is already amortised).
+    const bool pipelined = c->pipelineOn && !referenceOrder && !c->externalStream && !c->externalFramebuffers && rd->accumulationEnabled == 1 &&
+                           frames <= kPipelineMaxFrames;
     // The debug heat maps count the REFERENCE traversal's box/triangle checks (RaytracerCS.hlsl:516-520),
     // so those frames always run the reference-order kernel.
     if (referenceOrder) {
+        okrt_status js = joinStreams(c);
+        if (js != OKRT_OK) return js;
         if (tf) OKRT_HIP(c, hipEventRecord(tf->ev[0], c->stream));
         launchReferenceOrder(view, *rd, c->tile, c->accum, c->result, counters, c->stream);
         if (tf) OKRT_HIP(c, hipEventRecord(tf->ev[1], c->stream));
         used = 2;
+        c->accumChain = false;
     } else {
         std::string msg;
-        const LaunchStatus ls = launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, (unsigned long long*)c->counters.ptr, c->stream,
-                                           tf ? tf->ev.data() : nullptr, frames, msg);
+        LaunchOrder order;
+        if (pipelined) {
+            order.slot = c->pipeNext;
+            order.frameSlots = true;
+            order.after = c->accumChain ? c->accumDone[c->pipeLast] : nullptr;
+            order.done = c->accumDone[order.slot];
+            if (order.slot == 1u) {
+                launchStream = c->streamB;
+                if (c->needSyncB) {  // uploads, resets, ... made on the main stream since B last ran
+                    OKRT_HIP(c, hipEventRecord(c->evJoinA, c->stream));
+                    OKRT_HIP(c, hipStreamWaitEvent(c->streamB, c->evJoinA, 0));
+                    c->needSyncB = false;
+                }
+            }
+        } else {  // accumulates from inside its kernels, on the main stream: after everything B still has in flight
+            okrt_status js = joinStreams(c);
+            if (js != OKRT_OK) return js;
+        }
+        const LaunchStatus ls = launchFast(*c->fast, view, *rd, c->tile, c->accum, c->result, counters, (unsigned long long*)c->counters.ptr, launchStream,
+                                           tf ? tf->ev.data() : nullptr, frames, order, msg);
         if (ls != LaunchStatus::Ok)
             return fail(c, ls == LaunchStatus::OutOfMemory ? OKRT_ERR_OOM : ls == LaunchStatus::Invalid ? OKRT_ERR_INVALID_ARG : OKRT_ERR_DEVICE,
                         "fast pipeline: " + msg);
         used = 2 * (c->maxBounces + 1) + 1;
+        if (pipelined) {
+            c->bActive = c->bActive || order.slot == 1u;
+            c->pipeLast = order.slot;
+            c->pipeNext = order.slot ^ 1u;
+            c->accumChain = true;
+        } else {
+            c->accumChain = false;  // (stream order on the main stream covers it)
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, OKRT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -684,9 +755,9 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
         const size_t bytes = (size_t)c->tile.rows * c->W * 4;
         if (ensure(c, c->front[k], bytes) == OKRT_OK && bytes) {
             // (a peek may still be copying the picture this buffer held two launch sets ago: device-side wait, no host stall)
-            if (c->peekRecorded[k]) OKRT_HIP(c, hipStreamWaitEvent(c->stream, c->peekDone[k], 0));
-            OKRT_HIP(c, hipMemcpyAsync(c->front[k].ptr, c->result, bytes, hipMemcpyDeviceToDevice, c->stream));
-            OKRT_HIP(c, hipEventRecord(c->frontReady[k], c->stream));
+            if (c->peekRecorded[k]) OKRT_HIP(c, hipStreamWaitEvent(launchStream, c->peekDone[k], 0));
+            OKRT_HIP(c, hipMemcpyAsync(c->front[k].ptr, c->result, bytes, hipMemcpyDeviceToDevice, launchStream));
+            OKRT_HIP(c, hipEventRecord(c->frontReady[k], launchStream));
             c->frontValid[k] = true;
             c->frontFrames[k] = c->launchedFrames;
             c->frontNext = k ^ 1u;
@@ -745,6 +816,8 @@ okrt_status okrt_peek_result_rgba8(okrt_ctx* c, uint8_t* dst, uint32_t* out_fram
     if (pick < 0) {
         // nothing finished in a front buffer yet (first call, or right after a resize): the picture as of the last LAUNCHED
         // set, in stream order — still without executing deferred frames
+        okrt_status js = joinStreams(c);
+        if (js != OKRT_OK) return js;
         OKRT_HIP(c, hipMemcpyAsync(dst, c->result, bytes, hipMemcpyDeviceToHost, c->stream));
         OKRT_HIP(c, hipStreamSynchronize(c->stream));
         if (out_frames) *out_frames = c->launchedFrames;
@@ -799,6 +872,10 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             if (value < 0) return fail(c, OKRT_ERR_INVALID_ARG, "queue memory: MiB >= 0");
             fastSetQueueBudget(&c->fast, (size_t)value << 20);
             c->batchLimit = kMaxFramesPerLaunch;  // probe again from the top
+            return OKRT_OK;
+        case OKRT_OPT_PIPELINE:
+            if (value != 0 && value != 1) return fail(c, OKRT_ERR_INVALID_ARG, "pipeline: 0 or 1");
+            c->pipelineOn = value != 0 && c->streamB != nullptr;
             return OKRT_OK;
         case OKRT_OPT_DEBUG_FAIL_ALLOC:
             if (value < 0 || value > 1000) return fail(c, OKRT_ERR_INVALID_ARG, "debug fail alloc: 0..1000");

@@ -89,19 +89,24 @@ struct FastScene {
     bool allIdentity = true;
     DeviceBuilder* builder = nullptr;  // device-side build scratch (okrt_fast_build_device.hip), made on first use
     FastBuildInfo info = {};
-    // pipeline state, sized lazily for the tile
-    size_t capacity = 0, capacityQ0 = 0;  // items queue 1 + the hit records / queue 0 are allocated for
-    RayQueue q[2] = {};
-    HitBuffer hb = {};
-    uint32_t* counts = nullptr;  // per segment b, shard s: count at (b*kShards + s)*kCursorStride, cursor at kCursorBase + the same
-                                 // (every counter on its own 128-byte line: device-scope atomics serialise per line)
-    uint2* overflow = nullptr;
-    uint32_t overflowCap = 0;
+    // pipeline state of a launch set, sized lazily for the tile. Two slots: consecutive launch sets of a progressive
+    // accumulation may be in flight together on two streams (okrt_context.hip, OKRT_OPT_PIPELINE), each with its own
+    // queues, counters, spill slab and RenderData copy.
+    struct LaunchSlot {
+        size_t capacity = 0, capacityQ0 = 0;  // items queue 1 + the hit records / queue 0 are allocated for
+        RayQueue q[2] = {};
+        HitBuffer hb = {};
+        uint32_t* counts = nullptr;  // per segment b, shard s: count at (b*kShards + s)*kCursorStride, cursor at kCursorBase + the same
+                                     // (every counter on its own 128-byte line: device-scope atomics serialise per line)
+        uint2* overflow = nullptr;
+        uint32_t overflowCap = 0;
+        okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
+        float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
+        size_t radianceCap = 0;
+    } slot[2];
+    uint32_t overflowCap = 0;  // entries per thread the spill slabs need for the current tree
     int traceBlocks = 0, cus = 0;
     size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
-    okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
-    float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
-    size_t radianceCap = 0;
     uint4* tailHeaders = nullptr;  // tail drain (TailView): continuation headers and the stack-entry pool, reused by every segment
     uint2* tailEntries = nullptr;
     TailConst* tailConst = nullptr;  // device copy of the per-scene tail parameters
@@ -150,12 +155,7 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
     fs.cus = cus;
     fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : OKRT_TRACE_WAVES);
     uint32_t need = 3 * fs.maxDepth + 4;
-    uint32_t cap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;
-    if (cap != fs.overflowCap || !fs.overflow) {
-        if (!devAlloc(&fs.overflow, (size_t)fs.traceBlocks * kTraceThreads * cap, err)) return false;
-        fs.overflowCap = cap;
-    }
-    if (!fs.counts && !devAlloc(&fs.counts, kAllCountWords, err)) return false;
+    fs.overflowCap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;  // (the slabs themselves are made by the launch set that needs them)
     if (OKRT_TAIL_DRAIN) {
         if (getenv("OKRT_TAIL_PERCENT")) fs.tailPercent = (uint32_t)atoi(getenv("OKRT_TAIL_PERCENT"));
         if (!fs.tailHeaders && !devAlloc(&fs.tailHeaders, (size_t)kContinuations * 2, err)) return false;
@@ -217,18 +217,22 @@ void fastDestroy(FastScene* fs) {
     fs->nodes.release();
     fs->tris.release();
     if (fs->builder) deviceBuilderDestroy(fs->builder);
-    for (void* p : {(void*)fs->rdDev, (void*)fs->counts, (void*)fs->overflow, (void*)fs->hb.h, (void*)fs->hb.tri, (void*)fs->radiance, (void*)fs->tailHeaders,
-                    (void*)fs->tailEntries, (void*)fs->tailConst})
+    for (void* p : {(void*)fs->tailHeaders, (void*)fs->tailEntries, (void*)fs->tailConst})
         if (p) hipFree(p);
-    for (RayQueue& q : fs->q)
-        for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
+    for (FastScene::LaunchSlot& ls : fs->slot) {
+        for (void* p : {(void*)ls.rdDev, (void*)ls.counts, (void*)ls.overflow, (void*)ls.hb.h, (void*)ls.hb.tri, (void*)ls.radiance})
             if (p) hipFree(p);
+        for (RayQueue& q : ls.q)
+            for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
+                if (p) hipFree(p);
+    }
     delete fs;
 }
 
 LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
                         unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
-                        std::string& err) {
+                        const LaunchOrder& order, std::string& err) {
+    FastScene::LaunchSlot& ls = fs.slot[order.slot & 1u];
     const uint32_t perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
     if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)perFrame * frames > 0x7FFFFFFFull) {
         err = "frames per launch out of range";
@@ -251,51 +255,58 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     static const bool envPacket0 = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused0 = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
     const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2;
-    const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 ? (size_t)t.rows * t.W * frames * 16 : 0);
+    const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 || order.frameSlots ? (size_t)t.rows * t.W * frames * 16 : 0);
     if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
         err = "launch set exceeds the queue memory budget";
         return LaunchStatus::OutOfMemory;
     }
-    if (items > fs.capacity) {
+    if (items > ls.capacity) {
         hipStreamSynchronize(stream);
-        fs.capacity = fs.capacityQ0 = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
-        for (RayQueue* q : {&fs.q[0], &fs.q[1]})
+        ls.capacity = ls.capacityQ0 = 0;  // the old buffers are released first: a failed allocation must not leave a stale capacity behind
+        for (RayQueue* q : {&ls.q[0], &ls.q[1]})
             for (void** p : {(void**)&q->a, (void**)&q->b, (void**)&q->c, (void**)&q->d}) {
                 if (*p) hipFree(*p);
                 *p = nullptr;
             }
-        RayQueue& q = fs.q[1];
+        RayQueue& q = ls.q[1];
         if (!devAlloc(&q.a, items, err) || !devAlloc(&q.b, items, err) || !devAlloc(&q.c, items, err) || !devAlloc(&q.d, items, err)) return LaunchStatus::OutOfMemory;
-        if (!devAlloc(&fs.hb.h, items, err) || !devAlloc(&fs.hb.tri, items, err)) return LaunchStatus::OutOfMemory;
-        fs.capacity = items;
+        if (!devAlloc(&ls.hb.h, items, err) || !devAlloc(&ls.hb.tri, items, err)) return LaunchStatus::OutOfMemory;
+        ls.capacity = items;
     }
-    if (needQ0 && items > fs.capacityQ0) {
+    if (needQ0 && items > ls.capacityQ0) {
         hipStreamSynchronize(stream);
-        fs.capacityQ0 = 0;
-        RayQueue& q = fs.q[0];
-        if (!devAlloc(&q.a, fs.capacity, err) || !devAlloc(&q.b, fs.capacity, err) || !devAlloc(&q.c, fs.capacity, err) || !devAlloc(&q.d, fs.capacity, err))
+        ls.capacityQ0 = 0;
+        RayQueue& q = ls.q[0];
+        if (!devAlloc(&q.a, ls.capacity, err) || !devAlloc(&q.b, ls.capacity, err) || !devAlloc(&q.c, ls.capacity, err) || !devAlloc(&q.d, ls.capacity, err))
             return LaunchStatus::OutOfMemory;
-        fs.capacityQ0 = fs.capacity;
+        ls.capacityQ0 = ls.capacity;
     }
     const size_t pixels = (size_t)t.rows * t.W;
     float4* radiance = nullptr;
-    if (frames > 1) {
-        if (pixels * frames > fs.radianceCap) {
+    if (frames > 1 || order.frameSlots) {  // (a set that shares the GPU with its neighbour adds its radiance in a later, ordered step too)
+        if (pixels * frames > ls.radianceCap) {
             hipStreamSynchronize(stream);
-            fs.radianceCap = 0;
-            if (!devAlloc(&fs.radiance, pixels * frames, err)) return LaunchStatus::OutOfMemory;
-            fs.radianceCap = pixels * frames;
+            ls.radianceCap = 0;
+            if (!devAlloc(&ls.radiance, pixels * frames, err)) return LaunchStatus::OutOfMemory;
+            ls.radianceCap = pixels * frames;
         }
-        radiance = fs.radiance;
+        radiance = ls.radiance;
     }
     const uint32_t lastBounce = s.maxBounces;
     if (lastBounce + 2 > kMaxSegments) {
         err = "max_bounces too large for the fast pipeline";
         return LaunchStatus::Invalid;
     }
-    if (!fs.rdDev && !devAlloc(&fs.rdDev, 1, err)) return LaunchStatus::OutOfMemory;
-    if (hipFailed(hipMemsetAsync(fs.counts, 0, (size_t)kAllCountWords * sizeof(uint32_t), stream), "hipMemsetAsync(queue counters)")) return LaunchStatus::Device;
-    FastView fv{fs.nodes.p, fs.tris.p, fs.overflow, fs.overflowCap};
+    if (!ls.rdDev && !devAlloc(&ls.rdDev, 1, err)) return LaunchStatus::OutOfMemory;
+    if (!ls.counts && !devAlloc(&ls.counts, kAllCountWords, err)) return LaunchStatus::OutOfMemory;
+    if (!ls.overflow || ls.overflowCap != fs.overflowCap) {  // per-thread spill slab of this slot's trace kernels, sized for the current tree
+        hipStreamSynchronize(stream);
+        ls.overflowCap = 0;
+        if (!devAlloc(&ls.overflow, (size_t)fs.traceBlocks * kTraceThreads * fs.overflowCap, err)) return LaunchStatus::OutOfMemory;
+        ls.overflowCap = fs.overflowCap;
+    }
+    if (hipFailed(hipMemsetAsync(ls.counts, 0, (size_t)kAllCountWords * sizeof(uint32_t), stream), "hipMemsetAsync(queue counters)")) return LaunchStatus::Device;
+    FastView fv{fs.nodes.p, fs.tris.p, ls.overflow, ls.overflowCap};
     const dim3 tg(fs.traceBlocks);
     const dim3 sg((unsigned)(items / 256));
     const bool cnt = counters != nullptr;
@@ -309,8 +320,8 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     // (the refill threshold and the two step-block thresholds are compile-time constants of the trace kernel:
     // -DOKRT_REFILL_BELOW / -DOKRT_NODE_MIN / -DOKRT_TRI_MIN with tools/build_variant_all.sh; three fewer SGPRs live in its loop)
     auto shards = [&](uint32_t b, bool camera) {
-        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, camera ? nullptr : fs.counts + b * kShards * kCursorStride,
-                         fs.counts + kCursorBase + b * kShards * kCursorStride};
+        return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, camera ? nullptr : ls.counts + b * kShards * kCursorStride,
+                         ls.counts + kCursorBase + b * kShards * kCursorStride};
     };
     // tail drain: on when the drain kernel's shared stack is certain to hold a traversal of this tree (depth-first bound
     // 3 * depth + 4, twice over); a wave starts exporting once `tailPercent` % of the launch's waves have exited
@@ -325,7 +336,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
             return LaunchStatus::Device;
         fs.tailUploaded = exportAt;
     }
-    auto tail = [&](uint32_t b) { return TailView{tailOk ? fs.counts + kTailBase + b * kTailStride : nullptr, fs.tailConst}; };
+    auto tail = [&](uint32_t b) { return TailView{tailOk ? ls.counts + kTailBase + b * kTailStride : nullptr, fs.tailConst}; };
     static const bool dbgNoDrain = getenv("OKRT_DBG_NO_DRAIN") != nullptr;
     static const int envDrainBlocks = getenv("OKRT_TAIL_BLOCKS") ? atoi(getenv("OKRT_TAIL_BLOCKS")) : 16;
     const dim3 dg((unsigned)(dbgNoDrain ? 0 : fs.cus * envDrainBlocks));  // drain: one wave per block, 8 per CU; idle ones leave at once
@@ -337,39 +348,45 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
     // the launch set's RenderData in device memory, written by a kernel from its by-value argument: stream-ordered after
     // the previous launch set's readers, and no pageable-memory staging on the host side of an asynchronous call
-    launchSetRenderData(stream, rd, fs.rdDev);
-    const FusedArgs fa{perFrame, fs.q[1], fs.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, fs.rdDev};
+    launchSetRenderData(stream, rd, ls.rdDev);
+    const FusedArgs fa{perFrame, ls.q[1], ls.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, ls.rdDev};
     const uint32_t pixels32 = (uint32_t)pixels;
+    // the one step of a launch set that touches the accumulation: after the previous set's (another stream may carry it)
+    auto orderedAccumulate = [&]() {
+        if (order.after && he == hipSuccess) he = hipStreamWaitEvent(stream, order.after, 0);
+        launchAccumulate(stream, rd, pixels32, frames, radiance, accum, result);
+        if (order.done && he == hipSuccess) he = hipEventRecord(order.done, stream);
+    };
     if (packet && envFused) {
         // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
-        launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, fa);
         mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
     } else {
         // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
-        launchGenerate(sg, stream, rd, t, fs.q[0], perFrame, frames);
-        if (packet) launchPacket(cnt, false, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, fa);
+        launchGenerate(sg, stream, rd, t, ls.q[0], perFrame, frames);
+        if (packet) launchPacket(cnt, false, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, fa);
         else {
             const TailView tv = tail(0);
-            launchTrace(cnt, tg, stream, fv, s, rd, t, fs.q[0], fs.hb, shards(0, true), frames, counters, rayTotals, tv);
-            if (tv.ctr && dg.x) launchDrain(dg, stream, fv, fs.q[0], fs.hb, tv, fs.maxDepth);
+            launchTrace(cnt, tg, stream, fv, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, tv);
+            if (tv.ctr && dg.x) launchDrain(dg, stream, fv, ls.q[0], ls.hb, tv, fs.maxDepth);
         }
         mark();
-        launchShade(true, cnt, sg, stream, s, rd, t, fs.q[0], fs.hb, shards(0, true), fs.q[1], fs.counts + kShards * kCursorStride, 0u, lastBounce, accum, result,
+        launchShade(true, cnt, sg, stream, s, rd, t, ls.q[0], ls.hb, shards(0, true), ls.q[1], ls.counts + kShards * kCursorStride, 0u, lastBounce, accum, result,
                     radiance, counters);
     }
-    if (lastBounce == 0 && radiance) launchAccumulate(stream, rd, pixels32, frames, radiance, accum, result);
+    if (lastBounce == 0 && radiance) orderedAccumulate();
     mark();
     // segments 1..lastBounce: queue b lives in q[b & 1]
     for (uint32_t b = 1; b <= lastBounce; ++b) {
-        RayQueue& qin = fs.q[b & 1];
-        RayQueue& qout = fs.q[(b + 1) & 1];
+        RayQueue& qin = ls.q[b & 1];
+        RayQueue& qout = ls.q[(b + 1) & 1];
         const TailView tv = tail(b);
-        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, fs.hb, shards(b, false), 0u, counters, rayTotals, tv);
-        if (tv.ctr && dg.x) launchDrain(dg, stream, fv, qin, fs.hb, tv, fs.maxDepth);
+        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, ls.hb, shards(b, false), 0u, counters, rayTotals, tv);
+        if (tv.ctr && dg.x) launchDrain(dg, stream, fv, qin, ls.hb, tv, fs.maxDepth);
         mark();
-        launchShade(false, cnt, sg, stream, s, rd, t, qin, fs.hb, shards(b, false), qout, fs.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum,
+        launchShade(false, cnt, sg, stream, s, rd, t, qin, ls.hb, shards(b, false), qout, ls.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum,
                     result, radiance, counters);
-        if (b == lastBounce && radiance) launchAccumulate(stream, rd, pixels32, frames, radiance, accum, result);
+        if (b == lastBounce && radiance) orderedAccumulate();
         mark();
     }
     if (hipFailed(he, "hipEventRecord") || hipFailed(hipGetLastError(), "kernel launch")) return LaunchStatus::Device;

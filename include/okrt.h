@@ -159,7 +159,16 @@ typedef enum okrt_option {
     OKRT_OPT_QUEUE_MEMORY_MB = 6,
     /* Test hook: n > 0 = the n-th ray-queue allocation from now on fails as hipMalloc would when memory runs out (so that
      * the launch-set split on a REAL allocator failure can be tested); 0 = off. Process-wide. */
-    OKRT_OPT_DEBUG_FAIL_ALLOC = 7
+    OKRT_OPT_DEBUG_FAIL_ALLOC = 7,
+    /* 1 (default) = two launch sets in flight: consecutive launch sets that continue a progressive accumulation (fast
+     * traversal, no debug mode, library-owned stream and framebuffers, at most 32 frames each) alternate between two
+     * sets of ray queues and two HIP streams, so the next set's camera rays fill the GPU while the previous set's longest
+     * rays — a chain of dependent steps that no amount of parallelism shortens — are still draining. Only the accumulation
+     * is ordered between the sets (each adds its frames in one kernel that waits for the previous set's), so the
+     * framebuffers are bit-identical to one set at a time. Every entry point other than okrt_render / okrt_render_frames
+     * joins the two streams first: nothing else can observe the overlap. Footprint: the queues of TWO launch sets
+     * (2 x 3.0 GB at 1080p with the default deferral of 16 frames). 0 = one launch set at a time. */
+    OKRT_OPT_PIPELINE = 8
 } okrt_option;
 
 #define OKRT_BUILDER_HOST 0
