@@ -62,6 +62,7 @@ struct okrt_ctx {
     // streams, so the next set's bulk fills the GPU while the previous set's last rays drain. Only the accumulation is
     // ordered between them (accumDone events). Every entry point but the render calls joins stream B back into `stream`.
     bool pipelineOn = true, bActive = false, needSyncB = true, accumChain = false;
+    uint32_t pipelineMaxFrames = kPipelineDefaultFrames;  // launch sets up to this many frames alternate between the two slots
     hipStream_t streamB = nullptr;
     hipEvent_t accumDone[2] = {nullptr, nullptr}, evJoinA = nullptr, evJoinB = nullptr;
     uint32_t pipeNext = 0, pipeLast = 0;
@@ -691,10 +692,10 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
     hipStream_t launchStream = c->stream;
     // Two launch sets in flight: a set that merely continues a progressive accumulation takes the queue slot and stream
     // the previous set did NOT use, so its camera rays fill the GPU while that set's last bounce rays drain; its one
-    // accumulation kernel waits for the previous set's. Sets of more than kPipelineMaxFrames frames stay on one slot
-    // (two of them would double the largest queue footprint for a fixed cost that is already amortised).
+    // accumulation kernel waits for the previous set's. Larger sets (OKRT_OPT_PIPELINE) stay on one slot: their fixed
+    // cost is already amortised and two big persistent grids sharing the GPU cost more than the overlap returns.
     const bool pipelined = c->pipelineOn && !referenceOrder && !c->externalStream && !c->externalFramebuffers && rd->accumulationEnabled == 1 &&
-                           frames <= kPipelineMaxFrames;
+                           frames <= c->pipelineMaxFrames;
     // The debug heat maps count the REFERENCE traversal's box/triangle checks (RaytracerCS.hlsl:516-520),
     // so those frames always run the reference-order kernel.
     if (referenceOrder) {
@@ -874,8 +875,9 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             c->batchLimit = kMaxFramesPerLaunch;  // probe again from the top
             return OKRT_OK;
         case OKRT_OPT_PIPELINE:
-            if (value != 0 && value != 1) return fail(c, OKRT_ERR_INVALID_ARG, "pipeline: 0 or 1");
+            if (value < 0 || value > (int64_t)kPipelineMaxFrames) return fail(c, OKRT_ERR_INVALID_ARG, "pipeline: 0 (off) .. 32 frames per launch set");
             c->pipelineOn = value != 0 && c->streamB != nullptr;
+            if (value) c->pipelineMaxFrames = (uint32_t)value;
             return OKRT_OK;
         case OKRT_OPT_DEBUG_FAIL_ALLOC:
             if (value < 0 || value > 1000) return fail(c, OKRT_ERR_INVALID_ARG, "debug fail alloc: 0..1000");

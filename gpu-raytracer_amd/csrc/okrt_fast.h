@@ -145,6 +145,6 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
                         uint32_t* result, unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events,
                         uint32_t frames, const LaunchOrder& order, std::string& err);
 constexpr uint32_t kMaxFramesPerLaunch = 64;
-constexpr uint32_t kPipelineMaxFrames = 32;  // launch sets up to this size alternate between the two queue slots
+constexpr uint32_t kPipelineMaxFrames = 32, kPipelineDefaultFrames = 4;  // OKRT_OPT_PIPELINE: launch sets up to n frames alternate between the two queue slots
 
 }  // namespace okrt

@@ -10,21 +10,21 @@ for wl in (sys.argv[1:] or ["sponza"]):
     ctx = rt.ctx
     rt.renderFrames(64); rt.renderFrames(16); rt.renderFrames(16)
     out = []
-    for pipe in (0, 1):
+    for pipe in (0, 32):
         ctx.set_option(abi.OPT_PIPELINE, pipe)
-        for defer in (0, 16):
+        for defer in (0, 2, 4, 8, 16):
             ctx.set_option(abi.OPT_DEFER, defer)
             for _ in range(32): rt.render()
             ctx.synchronize()
             t = time.perf_counter()
             for _ in range(128): rt.render()
             ctx.synchronize()
-            out.append(f"pipeline {pipe} defer {defer}: {(time.perf_counter() - t) * 1e3 / 128:.4f}")
-        for F in (16, 32):
+            out.append(f"p{pipe} d{defer}: {(time.perf_counter() - t) * 1e3 / 128:.4f}")
+        for F in (32,):
             rt.renderFrames(F); ctx.synchronize()
             t = time.perf_counter()
             for _ in range(256 // F): rt.renderFrames(F)
             ctx.synchronize()
-            out.append(f"pipeline {pipe} sets of {F}: {(time.perf_counter() - t) * 1e3 / 256:.4f}")
+            out.append(f"p{pipe} sets of {F}: {(time.perf_counter() - t) * 1e3 / 256:.4f}")
     print(wl, "ms per frame |", " | ".join(out), flush=True)
     rt.close()
