@@ -72,7 +72,7 @@ constexpr int kLdsStack = OKRT_LDS_STACK;  // entries per lane kept in LDS
 constexpr uint32_t kHold = 0xFFFFFFFEu;  // traceDualKernel without speculation: "pop the stack when the parked leaf is done"
 constexpr uint32_t kDualTriMin = OKRT_DUAL_TRI_MIN;  // traceDualKernel: the triangle block runs once this many lanes hold a parked leaf
 constexpr int kRefillBelow = OKRT_REFILL_BELOW;  // refill idle lanes when fewer than this many lanes are active
-constexpr uint32_t kNodeMin = OKRT_NODE_MIN, kTriMin = OKRT_TRI_MIN;  // a step block runs when at least this many lanes want it
+constexpr uint32_t kNodeMin = OKRT_NODE_MIN, kTriMin = OKRT_TRI_MIN;  // OKRT_DUAL_POLICY=0: a step block runs when at least this many lanes want it
 constexpr uint32_t kDone = kEmptyRef;
 constexpr uint32_t kShards = 8;      // queue shards = XCDs
 constexpr uint32_t kBatch = 64;      // rays a wave reserves per cursor atomic (sweep: 64 best with 5 blocks/CU)
@@ -103,31 +103,6 @@ struct HitBuffer {
     uint32_t* tri;       // source triangle index (kInvalid for a sphere hit or a miss)
 };
 
-// Tail drain — an EXPERIMENT kept for the record, compiled only with -DOKRT_TAIL_DRAIN=1 (DESIGN.md "Measured dead ends":
-// it never paid for itself; the default build carries none of it). A persistent trace kernel ends when its LAST ray ends, and a ray is a chain of dependent steps: once the
-// queue is dry and most waves have left, the few rays with hundreds of steps run alone on an empty GPU (the kernel's fixed
-// cost: ~0.2 ms on the Sponza-class scene, ~1 ms on the 871k-triangle one). So a wave that is out of work watches how many
-// waves of the launch have exited; past `exportAt` it hands its unfinished rays over as CONTINUATIONS — best hit so far
-// plus the traversal stack — and exits too. drainKernel then finishes every continuation with a whole wave: the stack
-// entries are traversed 64 at a time (no front-to-back order needed: closerHit is order-independent), so a 300-step ray
-// takes a dozen iterations instead of 300.
-struct TailConst {        // per scene, in device memory (read only on the rare tail path: two SGPRs instead of a dozen)
-    uint4* headers;       // 2 x uint4 per continuation: {rayIdx, best, bu, bv}, {hitIdx, hitTri, entryBase, entryCount}
-    uint2* entries;       // (reference, entry distance) pool
-    uint32_t capHeaders, capEntries;
-    uint32_t exportAt;    // export once this many waves of the launch have exited ...
-    uint32_t maxLanes;    // ... or when this wave is down to so few live lanes (0 = never) ...
-    uint32_t afterIters;  // ... or has spent this many iterations since it ran out of work (0 = never)
-    uint32_t pad;
-};
-struct TailView {
-    // counters of ONE launch: ctr[s * kCursorStride] waves exited by XCD shard, then (at kShards, kShards + 1, kShards + 2
-    // strides) continuations exported, entry-pool cursor, drain cursor. nullptr = tail drain off.
-    uint32_t* ctr;
-    const TailConst* tc;
-};
-constexpr uint32_t kDrainStack = 1024;  // shared entries per drain wave (8 KB of LDS)
-
 struct FastView {
     const uint4* nodes;    // Node4Q as 4 x uint4
     const float4* tris;    // Tri48 as 3 x float4
@@ -149,20 +124,9 @@ OKRT_DEV bool shadeSegment(const SceneView& s, const okrt_render_data& rd, Ray& 
     return bounce < lastBounce;
 }
 
-// Does a triangle hit at distance d replace the current closest hit? Nearer wins (RaytracerCS.hlsl:316: strict <). With the
-// tail-drain experiment compiled in, equal distances are broken by (source triangle, instance) so that the result does not
-// depend on the order candidates are met in (a sphere hit keeps its tie like in the shader, :236 before :316).
-#ifndef OKRT_TAIL_DRAIN
-#define OKRT_TAIL_DRAIN 0
-#endif
-OKRT_DEV bool closerHit(float d, uint32_t tri, uint32_t inst, float best, uint32_t bestTri, uint32_t bestInst) {
-#if OKRT_TAIL_DRAIN
-    return d < best || (d == best && bestTri != kInvalid && (tri < bestTri || (tri == bestTri && inst < bestInst)));
-#else
-    (void)tri; (void)inst; (void)bestTri; (void)bestInst;
-    return d < best;  // first found wins (each kernel's visit order is deterministic per ray)
-#endif
-}
+// Does a triangle hit at distance d replace the current closest hit? Nearer wins (RaytracerCS.hlsl:316: strict <); among
+// equal distances the first one met stays (each kernel's visit order is deterministic per ray).
+OKRT_DEV bool closerHit(float d, uint32_t, uint32_t, float best, uint32_t, uint32_t) { return d < best; }
 
 // primary ray index -> pixel (8x8 tiles, row-major over tiles)
 OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t& lrow) {
@@ -193,9 +157,7 @@ struct FusedArgs {
 // ---- launch wrappers (one per kernel family; `count` selects the variant that feeds okrt_counters) --------------------
 void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames);
 void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
-                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals,
-                 const TailView& tv);
-void launchDrain(dim3 grid, hipStream_t stream, const FastView& fv, RayQueue q, HitBuffer hb, const TailView& tv, uint32_t maxDepth);
+                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals);
 void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,
                   const okrt_render_data& rd, const TileView& tile, RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames,
                   unsigned long long* counters, unsigned long long* rayTotals, const FusedArgs& fa);

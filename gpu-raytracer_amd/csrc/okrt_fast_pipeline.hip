@@ -75,12 +75,7 @@ bool devAlloc(T** p, size_t n, std::string& err) {
 constexpr uint32_t kMaxSegments = 66;                       // max_bounces <= 64
 constexpr uint32_t kCursorBase = kMaxSegments * kShards * kCursorStride;
 constexpr uint32_t kCountWords = kCursorBase + kMaxSegments * kShards * kCursorStride;
-// tail-drain counters of segment b (TailView): kShards exit counters, then continuation count / entry cursor / drain cursor
-constexpr uint32_t kTailStride = (kShards + 8) * kCursorStride;
-constexpr uint32_t kTailBase = kCountWords;
-constexpr uint32_t kAllCountWords = kTailBase + (OKRT_TAIL_DRAIN ? kMaxSegments * kTailStride : 0u);  // (the experiment's counters only exist in its build)
-constexpr uint32_t kContinuations = 1u << 17;       // continuation headers per segment launch (32 B each)
-constexpr uint32_t kContinuationEntries = 1u << 22; // stack entries in the pool (8 B each)
+constexpr uint32_t kAllCountWords = kCountWords;
 
 struct FastScene {
     DeviceArray<uint4> nodes;   // 4 x uint4 per Node4Q
@@ -107,11 +102,6 @@ struct FastScene {
     uint32_t overflowCap = 0;  // entries per thread the spill slabs need for the current tree
     int traceBlocks = 0, cus = 0;
     size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
-    uint4* tailHeaders = nullptr;  // tail drain (TailView): continuation headers and the stack-entry pool, reused by every segment
-    uint2* tailEntries = nullptr;
-    TailConst* tailConst = nullptr;  // device copy of the per-scene tail parameters
-    uint32_t tailPercent = 97;     // (-DOKRT_TAIL_DRAIN=1 builds) export once this share of a launch's waves has exited; OKRT_TAIL_PERCENT
-    uint32_t tailUploaded = ~0u;   // the exportAt value tailConst holds
 };
 
 bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& tables, uint32_t builder, hipStream_t stream, std::string& err) {
@@ -156,13 +146,6 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
     fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : OKRT_TRACE_WAVES);
     uint32_t need = 3 * fs.maxDepth + 4;
     fs.overflowCap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;  // (the slabs themselves are made by the launch set that needs them)
-    if (OKRT_TAIL_DRAIN) {
-        if (getenv("OKRT_TAIL_PERCENT")) fs.tailPercent = (uint32_t)atoi(getenv("OKRT_TAIL_PERCENT"));
-        if (!fs.tailHeaders && !devAlloc(&fs.tailHeaders, (size_t)kContinuations * 2, err)) return false;
-        if (!fs.tailEntries && !devAlloc(&fs.tailEntries, kContinuationEntries, err)) return false;
-        if (!fs.tailConst && !devAlloc(&fs.tailConst, 1, err)) return false;
-    }
-    fs.tailUploaded = ~0u;
     return true;
 }
 
@@ -217,8 +200,6 @@ void fastDestroy(FastScene* fs) {
     fs->nodes.release();
     fs->tris.release();
     if (fs->builder) deviceBuilderDestroy(fs->builder);
-    for (void* p : {(void*)fs->tailHeaders, (void*)fs->tailEntries, (void*)fs->tailConst})
-        if (p) hipFree(p);
     for (FastScene::LaunchSlot& ls : fs->slot) {
         for (void* p : {(void*)ls.rdDev, (void*)ls.counts, (void*)ls.overflow, (void*)ls.hb.h, (void*)ls.hb.tri, (void*)ls.radiance})
             if (p) hipFree(p);
@@ -323,23 +304,6 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         return ShardView{cap, camera ? total : 0u, envBatch, envAffinity, camera ? nullptr : ls.counts + b * kShards * kCursorStride,
                          ls.counts + kCursorBase + b * kShards * kCursorStride};
     };
-    // tail drain: on when the drain kernel's shared stack is certain to hold a traversal of this tree (depth-first bound
-    // 3 * depth + 4, twice over); a wave starts exporting once `tailPercent` % of the launch's waves have exited
-    const uint32_t traceWaves = (uint32_t)fs.traceBlocks * (kTraceThreads / 64);
-    const bool tailOk = OKRT_TAIL_DRAIN && fs.tailPercent > 0 && 2u * (3u * fs.maxDepth + 8u) <= kDrainStack;
-    const uint32_t exportAt = tailOk ? std::max<uint32_t>((uint32_t)(((uint64_t)traceWaves * fs.tailPercent + 99) / 100), 1u) : 0u;
-    if (tailOk && fs.tailUploaded != exportAt) {  // (scene build or option change: rare, synchronous)
-        static const uint32_t envLanes = getenv("OKRT_TAIL_LANES") ? (uint32_t)atoi(getenv("OKRT_TAIL_LANES")) : 0u;
-        static const uint32_t envIters = getenv("OKRT_TAIL_ITERS") ? (uint32_t)atoi(getenv("OKRT_TAIL_ITERS")) : 0u;
-        const TailConst tc{fs.tailHeaders, fs.tailEntries, kContinuations, kContinuationEntries, exportAt, envLanes, envIters, 0u};
-        if (hipFailed(hipStreamSynchronize(stream), "hipStreamSynchronize") || hipFailed(hipMemcpy(fs.tailConst, &tc, sizeof(tc), hipMemcpyHostToDevice), "hipMemcpy(tail)"))
-            return LaunchStatus::Device;
-        fs.tailUploaded = exportAt;
-    }
-    auto tail = [&](uint32_t b) { return TailView{tailOk ? ls.counts + kTailBase + b * kTailStride : nullptr, fs.tailConst}; };
-    static const bool dbgNoDrain = getenv("OKRT_DBG_NO_DRAIN") != nullptr;
-    static const int envDrainBlocks = getenv("OKRT_TAIL_BLOCKS") ? atoi(getenv("OKRT_TAIL_BLOCKS")) : 16;
-    const dim3 dg((unsigned)(dbgNoDrain ? 0 : fs.cus * envDrainBlocks));  // drain: one wave per block, 8 per CU; idle ones leave at once
     mark();
     static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
@@ -365,11 +329,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
         launchGenerate(sg, stream, rd, t, ls.q[0], perFrame, frames);
         if (packet) launchPacket(cnt, false, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, fa);
-        else {
-            const TailView tv = tail(0);
-            launchTrace(cnt, tg, stream, fv, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, tv);
-            if (tv.ctr && dg.x) launchDrain(dg, stream, fv, ls.q[0], ls.hb, tv, fs.maxDepth);
-        }
+        else launchTrace(cnt, tg, stream, fv, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals);
         mark();
         launchShade(true, cnt, sg, stream, s, rd, t, ls.q[0], ls.hb, shards(0, true), ls.q[1], ls.counts + kShards * kCursorStride, 0u, lastBounce, accum, result,
                     radiance, counters);
@@ -380,9 +340,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     for (uint32_t b = 1; b <= lastBounce; ++b) {
         RayQueue& qin = ls.q[b & 1];
         RayQueue& qout = ls.q[(b + 1) & 1];
-        const TailView tv = tail(b);
-        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, ls.hb, shards(b, false), 0u, counters, rayTotals, tv);
-        if (tv.ctr && dg.x) launchDrain(dg, stream, fv, qin, ls.hb, tv, fs.maxDepth);
+        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, ls.hb, shards(b, false), 0u, counters, rayTotals);
         mark();
         launchShade(false, cnt, sg, stream, s, rd, t, qin, ls.hb, shards(b, false), qout, ls.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum,
                     result, radiance, counters);

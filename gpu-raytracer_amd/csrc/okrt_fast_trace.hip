@@ -1,397 +1,28 @@
 // okrt_fast_trace.hip — the traversal kernels of the wavefront pipeline (okrt_fast_pipeline.hip has the overview):
-//   traceKernel         per-ray, persistent, "if-if" scheduling: every segment but the camera one
+//   traceKernel         per-ray, persistent, one step per lane and iteration: every segment but the camera one
 //   tracePacketKernel   one wave per 8x8 pixel tile; FUSED = the whole camera segment (generate, trace, shade, append)
 //   fastKatKernel       one thread per ray, the known-answer probe
-#include <cstdlib>
-
 #include "okrt_fast_internal.h"
 
 namespace okrt {
 namespace fastdetail {
 namespace {
 
+// ---- per-ray traversal ---------------------------------------------------------------------------------------------
+// Persistent waves; every iteration a lane does ONE unit of work, a node visit or a triangle test ("if-if" scheduling;
+// the first version descended while-while — all node steps, then the whole leaf — and the lanes of a wave, which need
+// very different numbers of steps before their next leaf, waited for the slowest one). A lane's pending work sits in two
+// registers: `cur`, the node to visit next, and `leaf`, the leaf whose triangles are being tested; the wave runs ONE
+// step block per iteration, the one more lanes can join (triangles from kDualTriMin takers, or when they outnumber the
+// nodes), and all loads of the block are issued through one pointer per lane before anything is computed. Round 3
+// measurements that shaped it (Sponza-class / 871 k-triangle scene, bounce trace ms per frame, 64-frame sets):
+//   round-2 kernel (both blocks per iteration above lane thresholds, flat-addressed pops)        0.274 / 0.152
+//   this loop                                                                                    0.252 / 0.140
+//   ... with a parked leaf while the lane traverses on (OKRT_DUAL_SPECULATE=1: +9 % node visits)  0.282 / 0.163
+//   ... both blocks in one iteration above thresholds (OKRT_DUAL_POLICY=0)                        0.269 / 0.143
+//   ... 8 waves per SIMD (64 VGPRs: 48-56 B of scratch in the loop)                               0.659 / 0.383
 template <bool COUNT>
-__global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceKernel(FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q,
-                                                            HitBuffer hb, ShardView sv, uint32_t cameraFrames,
-                                                            unsigned long long* counters, unsigned long long* rayTotals, TailView tv) {
-    // (ref, entry distance) pairs, [entry][thread]; row kLdsStack is a dummy target for predicated-off pushes
-    __shared__ uint2 sStack[kLdsStack + 1][kTraceThreads];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    uint2* myOverflow = fv.overflow + (size_t)(blockIdx.x * kTraceThreads + tid) * fv.overflowCap;
-    if (!COUNT && blockIdx.x == 0 && tid == 0) {  // rays of this launch, always counted (okrt_counters.pixels / .segments)
-        unsigned long long n = 0;
-        if (cameraFrames) n = (unsigned long long)tile.W * tile.rows * cameraFrames;
-        else for (uint32_t k = 0; k < kShards; ++k) n += sv.count(k);
-        if (cameraFrames) atomicAdd(&rayTotals[0], n);
-        atomicAdd(&rayTotals[1], n);
-    }
-    // wave-uniform work-fetch state
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    uint32_t shard = sv.xcdAffinity ? (xcc & (kShards - 1)) : 0u, tried = 0, resNext = 0, resEnd = 0;
-    uint32_t preRaw = 0, preShard = 0;  // prefetched reservation: preRaw is only meaningful in lane 0
-    bool havePre = false;
-
-    uint32_t rayIdx = kInvalid;   // the ray this lane is tracing
-    uint32_t cur = kDone;         // node/leaf reference being processed, kDone = nothing
-    uint32_t triJ = 0;            // cur is a leaf: the triangle to test next
-    uint32_t sp = 0;
-    V3 ro = mk(0, 0, 0), rdir = mk(0, 0, 0), iq = mk(0, 0, 0);
-    float best = kFltMax, hbu = 0.f, hbv = 0.f;
-    uint32_t hitIdx = kInvalid, hitTri = kInvalid;
-    uint32_t nNodes = 0, nTris = 0, nSeg = 0;
-    bool exhausted = false;
-#ifdef OKRT_STAMPS_BLOCKS  // diagnostic build: wave-level executions of the two step blocks and the lanes that took part (tools/stamps2.py)
-    unsigned long long stNodeWave = 0, stNodeLane = 0, stTriWave = 0, stTriLane = 0, stIter = 0, stLive = 0;
-#endif
-#if OKRT_TAIL_DRAIN
-    uint32_t tailIter = 0;        // iterations since this wave ran out of work (wave-uniform)
-    bool tailOpen = tv.ctr != nullptr;
-#endif
-#ifdef OKRT_ITER_HIST  // diagnostic build: steps per ray, histogrammed into counters[2..9] (<=16, <=32, ... <=1024, more) and the maximum into [0] is left alone
-    uint32_t raySteps = 0;
-#define OKRT_HIST_STEP raySteps++;
-#define OKRT_HIST_DONE if (COUNT && counters) { uint32_t b_ = 0; while (b_ < 7 && raySteps > (16u << b_)) b_++; atomicAdd(&counters[2 + b_], 1ull); atomicMax(&counters[10], (unsigned long long)raySteps); } raySteps = 0;
-#else
-#define OKRT_HIST_STEP
-#define OKRT_HIST_DONE
-#endif
-
-#ifdef OKRT_STAMPS
-    unsigned long long tRefill = 0, tInner = 0, tLeaf = 0, tStart = __builtin_amdgcn_s_memtime(), nRefill = 0, nIter = 0, laneIters = 0;
-    unsigned long long nodeWave = 0, nodeLane = 0, leafWave = 0, leafLane = 0;  // wave-iterations and active lane-iterations of the two step blocks
-#define OKRT_T0 unsigned long long t0_ = __builtin_amdgcn_s_memtime();
-#define OKRT_T1(acc) acc += __builtin_amdgcn_s_memtime() - t0_;
-#else
-#define OKRT_T0
-#define OKRT_T1(acc)
-#endif
-    // pop the next entry the current best does not already beat
-    auto popNext = [&]() -> uint32_t {
-        while (sp > 0) {
-            --sp;
-            const uint2 e = sp < (uint32_t)kLdsStack ? sStack[sp][tid] : myOverflow[sp - kLdsStack];
-            if (__uint_as_float(e.y) < best) return e.x;
-        }
-        return kDone;
-    };
-    for (;;) {
-#ifdef OKRT_STAMPS
-        nIter++;
-        laneIters += __popcll(__ballot(cur != kDone));
-#endif
-        // ---- refill: lanes whose traversal ended store their hit and take the next rays --------
-        const unsigned long long idle = __ballot(cur == kDone);
-        if ((uint32_t)__popcll(~idle) < (uint32_t)kRefillBelow) {
-            OKRT_T0
-#ifdef OKRT_STAMPS
-            nRefill++;
-#endif
-            if (cur == kDone && rayIdx != kInvalid) {
-                stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
-                stStream(&hb.tri[rayIdx], hitTri);
-                rayIdx = kInvalid;
-                OKRT_HIST_DONE
-            }
-            for (int round = 0; round < 2 && !exhausted; ++round) {
-                const unsigned long long need = __ballot(cur == kDone);
-                if (!need) break;
-                if (resNext == resEnd) {  // take the prefetched reservation (wave-uniform); steal when a shard is dry
-                    while (tried < kShards) {
-                        if (!havePre) {
-                            if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], sv.batch ? sv.batch : (uint32_t)__popcll(need));
-                            preShard = shard;
-                            havePre = true;
-                        }
-                        const uint32_t bpos = __builtin_amdgcn_readfirstlane(preRaw);  // waits for the atomic here
-                        const uint32_t cnt = sv.count(preShard);
-                        havePre = false;
-                        if (bpos < cnt) {
-                            resNext = preShard * sv.cap + bpos;
-                            resEnd = preShard * sv.cap + min(bpos + (sv.batch ? sv.batch : (uint32_t)__popcll(need)), cnt);
-                            tried = 0;
-                            break;
-                        }
-                        // this shard is dry: look at all cursors with ONE load (lane k reads shard k) and jump to the
-                        // next shard that still has rays, instead of probing each with a returning atomic
-                        uint32_t seen = 0xFFFFFFFFu, lim = 0;
-                        if (lane < kShards) {
-                            seen = __hip_atomic_load(&sv.cursors[lane * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            lim = sv.count(lane);
-                        }
-                        const uint32_t live = (uint32_t)__ballot(seen < lim) & ((1u << kShards) - 1u);
-                        if (!live) {
-                            tried = kShards;
-                            break;
-                        }
-                        const uint32_t rot = ((live >> shard) | (live << (kShards - shard))) & ((1u << kShards) - 1u);  // bit j = shard+j
-                        shard = (shard + (uint32_t)__builtin_ctz(rot)) & (kShards - 1);
-                        tried++;
-                    }
-                    if (resNext == resEnd) {
-                        exhausted = true;
-                        break;
-                    }
-                    if (sv.batch) {  // issue the NEXT reservation now; its round trip overlaps the traversal of this batch
-                        if (lane == 0) preRaw = atomicAdd(&sv.cursors[shard * kCursorStride], sv.batch);
-                        preShard = shard;
-                        havePre = true;
-                    }
-                }
-                const uint32_t avail = resEnd - resNext;
-                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (cur == kDone && rank < avail) {
-                    const uint32_t mine = resNext + rank;
-                    const float4 A = ldStream(&q.a[mine]), B = ldStream(&q.b[mine]);
-                    Ray ray;
-                    ray.origin = mk(A.x, A.y, A.z);
-                    ray.direction = mk(A.w, B.x, B.y);
-                    if (__float_as_uint(B.w) != kInvalid) {  // camera-ray padding outside the image carries pix = kInvalid
-                        rayIdx = mine;
-                        nSeg++;
-                        ro = ray.origin;
-                        // the shader re-normalises the direction per instance (RaytracerCS.hlsl:276)
-                        rdir = normalize(ray.direction);
-                        iq = rcp3(rdir);  // clamped to +-1e30 so that 0 * inf cannot poison the fused slab arithmetic
-                        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
-                        best = kFltMax;
-                        hitIdx = kInvalid;
-                        hitTri = kInvalid;
-                        hbu = hbv = 0.f;
-                        for (uint32_t i = 0; i < rd.numSpheres; i++) {  // RaytracerCS.hlsl:232-242 (original direction)
-                            float d = rayAndSphere(ray, ld3(s.spheres[i].position), s.spheres[i].radius);
-                            if (d > 0.f && d < best) {
-                                best = d;
-                                hitIdx = i;
-                            }
-                        }
-                        sp = 0;
-                        cur = 0;  // root node
-                    }
-                }
-                resNext += min((uint32_t)__popcll(need), avail);
-            }
-            OKRT_T1(tRefill)
-            if (__ballot(rayIdx != kInvalid) == 0ull) break;  // queues drained and every lane idle
-        }
-
-#if OKRT_TAIL_DRAIN
-        // ---- tail: out of work and nearly alone on the GPU -> hand the unfinished rays to the drain kernel -------------
-        if (exhausted && tailOpen && (++tailIter & 3u) == 0u) {
-            uint32_t gone = lane < kShards ? __hip_atomic_load(&tv.ctr[lane * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            gone += __shfl_xor(gone, 1, 64);
-            gone += __shfl_xor(gone, 2, 64);
-            gone += __shfl_xor(gone, 4, 64);
-            const TailConst tc = *tv.tc;
-            const bool live = cur != kDone;
-            const unsigned long long em = __ballot(live);
-            if ((uint32_t)__builtin_amdgcn_readfirstlane(gone) >= tc.exportAt || (uint32_t)__popcll(em) <= tc.maxLanes || (tc.afterIters && tailIter >= tc.afterIters)) {
-                if (em) {
-                    uint32_t* cont = tv.ctr + kShards * kCursorStride;
-                    const uint32_t n = sp + 1u;  // the stack plus the reference in hand
-                    uint32_t slot0 = 0;
-                    if (lane == (uint32_t)__ffsll((long long)em) - 1u) slot0 = atomicAdd(&cont[0], (uint32_t)__popcll(em));
-                    slot0 = __shfl(slot0, __ffsll((long long)em) - 1, 64);
-                    const uint32_t slot = slot0 + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                    uint32_t ebase = 0;
-                    if (live && slot < tc.capHeaders) ebase = atomicAdd(&cont[kCursorStride], n);
-                    const bool fits = live && slot < tc.capHeaders && (uint64_t)ebase + n <= tc.capEntries;
-                    if (live && slot < tc.capHeaders) {  // a reserved header is always written: an empty one tells the drain to skip it
-                        tc.headers[2 * (size_t)slot] = make_uint4(fits ? rayIdx : kInvalid, __float_as_uint(best), __float_as_uint(hbu), __float_as_uint(hbv));
-                        tc.headers[2 * (size_t)slot + 1] = make_uint4(hitIdx, hitTri, ebase, fits ? n : 0u);
-                    }
-                    if (fits) {
-                        for (uint32_t k = 0; k < sp; ++k) tc.entries[ebase + k] = k < (uint32_t)kLdsStack ? sStack[k][tid] : myOverflow[k - kLdsStack];
-                        tc.entries[ebase + sp] = make_uint2(cur, 0u);  // (a leaf in progress is simply tested again from its first triangle)
-                        cur = kDone;
-                        rayIdx = kInvalid;  // the drain kernel writes this ray's hit record
-                        OKRT_HIST_DONE
-                    }
-                    if (__ballot(live && !fits)) tailOpen = false;  // pools full: finish here
-                }
-            }
-        }
-#endif
-
-        // ---- one step per lane: a node visit OR a triangle test ("if-if" scheduling) ------------------------------
-        // The first version descended in a while-while loop (all node steps, then all leaf triangles); with bounce
-        // rays the lanes of a wave need very different numbers of steps before their next leaf and waited for the
-        // slowest one. Here every lane does exactly one unit of work per iteration, whichever it needs; a block is
-        // skipped when fewer than nodeMin / triMin lanes want it and the other block has work (those lanes wait one
-        // round and join a fuller block). All loads of the iteration are issued together, through one pointer per
-        // lane, before either block computes.
-        const bool isNode = cur != kDone && !(cur & kLeafBit);
-        const bool isTri = cur != kDone && (cur & kLeafBit);
-        const uint32_t wantNode = (uint32_t)__popcll(__ballot(isNode)), wantTri = (uint32_t)__popcll(__ballot(isTri));
-        bool runNode = wantNode >= kNodeMin, runTri = wantTri >= kTriMin;
-        if (!runNode && !runTri) {
-            runNode = wantNode >= wantTri && wantNode;
-            runTri = !runNode && wantTri;
-        }
-        const bool stepNode = isNode && runNode, stepTri = isTri && runTri;
-#ifdef OKRT_STAMPS_BLOCKS
-        stIter++;
-        stLive += __popcll(__ballot(cur != kDone));
-        if (runNode) { stNodeWave++; stNodeLane += wantNode; }
-        if (runTri) { stTriWave++; stTriLane += wantTri; }
-#endif
-        uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, d2 = d0, d3 = d0;
-        if (stepNode || stepTri) {
-            const uint4* p = stepNode ? fv.nodes + (size_t)cur * 4 : (const uint4*)fv.tris + (size_t)((cur & 0x07FFFFFFu) + triJ) * 3;
-            d0 = p[0];
-            d1 = p[1];
-            d2 = p[2];
-            if (stepNode) d3 = p[3];
-        }
-        if (stepNode) {
-            OKRT_T0
-#ifdef OKRT_STAMPS
-            nodeLane++;
-            if ((int)lane == __ffsll((long long)__ballot(true)) - 1) nodeWave++;
-#endif
-            const uint4 n0 = d0, n1 = d1, n2 = d2, n3 = d3;
-            if (COUNT) nNodes++;
-            OKRT_HIST_STEP
-            float tn[4];
-            uint32_t ch[4] = {n1.x, n1.y, n1.z, n1.w};
-            // slab test on the node's grid: t = (origin + q*step - o)/d = fma(q, step/d, (origin - o)/d)
-            const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
-            const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
-            const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
-            // entry planes are the lower ones for a positive direction component, the upper ones otherwise
-            const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
-            const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
-            const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
-                                          fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
-                const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
-                                         fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
-                bool hit = tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef;
-                tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
-            }
-            // sort the four (distance, child) pairs ascending: 5-comparator network, select-based (no branches)
-#define OKRT_CSWAP(i, j)                                              \
-    {                                                                 \
-        const bool sw_ = tn[j] < tn[i];                               \
-        const float lo_ = sw_ ? tn[j] : tn[i], hi_ = sw_ ? tn[i] : tn[j];     \
-        const uint32_t cl_ = sw_ ? ch[j] : ch[i], chh_ = sw_ ? ch[i] : ch[j]; \
-        tn[i] = lo_; tn[j] = hi_; ch[i] = cl_; ch[j] = chh_;          \
-    }
-            OKRT_CSWAP(0, 1) OKRT_CSWAP(2, 3) OKRT_CSWAP(0, 2) OKRT_CSWAP(1, 3) OKRT_CSWAP(1, 2)
-#undef OKRT_CSWAP
-            // hits are now ch[0..n-1]; push n-1 far ones so that ch[1] ends on top, continue with ch[0]
-            const uint32_t n = (tn[0] < kFltMax) + (tn[1] < kFltMax) + (tn[2] < kFltMax) + (tn[3] < kFltMax);
-            if (sp + 3 <= (uint32_t)kLdsStack) {  // fast path: three unconditional 8-byte LDS writes, misses go to the dummy row
-                const uint32_t top = sp + n;      // entry k (1..n-1) lands at sp + n-1-k
-                sStack[1 < n ? top - 2 : kLdsStack][tid] = make_uint2(ch[1], __float_as_uint(tn[1]));
-                sStack[2 < n ? top - 3 : kLdsStack][tid] = make_uint2(ch[2], __float_as_uint(tn[2]));
-                sStack[3 < n ? top - 4 : kLdsStack][tid] = make_uint2(ch[3], __float_as_uint(tn[3]));
-                sp += n > 1 ? n - 1 : 0;
-            } else {  // deep in the tree: spill to the per-thread HBM slab
-#pragma unroll
-                for (int k = 3; k >= 1; --k) {
-                    if (tn[k] < kFltMax) {
-                        if (sp < (uint32_t)kLdsStack) {
-                            sStack[sp][tid] = make_uint2(ch[k], __float_as_uint(tn[k]));
-                        } else if (sp - kLdsStack < fv.overflowCap) {
-                            myOverflow[sp - kLdsStack] = make_uint2(ch[k], __float_as_uint(tn[k]));
-#ifdef OKRT_ITER_HIST
-                            if (COUNT && counters) atomicAdd(&counters[11], 1ull);  // diagnostic: stack entries spilled to the HBM slab
-#endif
-                        } else {
-                            continue;  // cannot happen: the slab is sized from the tree depth
-                        }
-                        sp++;
-                    }
-                }
-            }
-            cur = n ? ch[0] : popNext();
-            triJ = 0;
-            OKRT_T1(tInner)
-        }
-        if (stepTri) {  // Moeller-Trumbore on triangle triJ of the leaf
-            OKRT_T0
-#ifdef OKRT_STAMPS
-            leafLane++;
-            if ((int)lane == __ffsll((long long)__ballot(true)) - 1) leafWave++;
-#endif
-            if (COUNT) nTris++;
-            OKRT_HIST_STEP
-            float bu = 0.f, bv = 0.f;
-            const float t = rayAndTriangleEdges(ro, rdir, mk(__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)),
-                                                mk(__uint_as_float(d1.x), __uint_as_float(d1.y), __uint_as_float(d1.z)),
-                                                mk(__uint_as_float(d2.x), __uint_as_float(d2.y), __uint_as_float(d2.z)), bu, bv);
-            if (t > 0.f) {
-                const float d = length(rdir * t);  // RaytracerCS.hlsl:311-314 with M = identity (world-space triangles)
-                if (closerHit(d, d0.w, d1.w, best, hitTri, hitIdx)) {
-                    best = d;
-                    hbu = bu;
-                    hbv = bv;
-                    hitTri = d0.w;
-                    hitIdx = d1.w;
-                }
-            }
-            if (++triJ > ((cur >> 27) & 15u)) {  // count - 1 is stored
-                cur = popNext();
-                triJ = 0;
-            }
-            OKRT_T1(tLeaf)
-        }
-    }
-
-#if OKRT_TAIL_DRAIN
-    if (tv.ctr && lane == 0) atomicAdd(&tv.ctr[(xcc & (kShards - 1)) * kCursorStride], 1u);  // this wave is done
-#endif
-#ifdef OKRT_STAMPS
-    for (int off = 32; off > 0; off >>= 1) {
-        nodeWave += __shfl_down(nodeWave, off, 64); nodeLane += __shfl_down(nodeLane, off, 64);
-        leafWave += __shfl_down(leafWave, off, 64); leafLane += __shfl_down(leafLane, off, 64);
-    }
-    if (COUNT && counters && lane == 0) {  // cycle sums per wave: n_oct=refill, n_mesh=inner, n_node=leaf, n_tri=total, mesh_hits=#refills, sphere_hits=#iters, tex_taps=active lane-iters
-#ifdef OKRT_STAMPS_ITERS  // outer iterations and live lanes per iteration instead of the refill / leaf cycle sums
-        atomicAdd(&counters[2], laneIters); atomicAdd(&counters[3], tInner); atomicAdd(&counters[4], nIter);
-#else
-        atomicAdd(&counters[2], tRefill); atomicAdd(&counters[3], tInner); atomicAdd(&counters[4], tLeaf);
-#endif
-        atomicAdd(&counters[5], __builtin_amdgcn_s_memtime() - tStart);
-        atomicAdd(&counters[6], nodeWave); atomicAdd(&counters[7], nodeLane); atomicAdd(&counters[8], leafWave); atomicAdd(&counters[9], leafLane);
-    }
-#endif
-#ifdef OKRT_STAMPS_BLOCKS
-    if (COUNT && counters && lane == 0) {
-        atomicAdd(&counters[0], stLive);
-        atomicAdd(&counters[1], stIter << 32);  // (iterations ride in the high half of `segments`)
-        atomicAdd(&counters[2], stNodeWave); atomicAdd(&counters[3], stNodeLane); atomicAdd(&counters[4], stTriWave); atomicAdd(&counters[5], stTriLane);
-    }
-#endif
-#ifndef OKRT_ITER_HIST
-    if (COUNT && counters) {
-        uint32_t vals[3] = {nSeg, nNodes, nTris};
-        const int slot[3] = {1, 10, 11};  // segments, fast_nodes, fast_tris
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            uint32_t v = vals[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
-        }
-    }
-#endif
-}
-
-// ---- per-ray traversal, two work slots per lane ("dual") -------------------------------------------------------------
-// traceKernel above gives a lane ONE unit of work per iteration — a node visit or a triangle test — and runs both step
-// blocks whenever enough lanes want each: a lane whose ray reached a leaf waits for the triangle block while the node
-// block runs half empty, and the other way round (VALU lane utilisation 0.56). Here a lane holds up to TWO pending
-// units, a node reference in `cur` and a leaf in `leaf`: a ray that reaches a leaf parks it and goes on down the tree
-// with whatever its stack holds next, so nearly every live lane can join whichever block the wave decides to run, and
-// the wave runs ONE block per iteration, the one with more takers. The parked leaf is tested a few iterations later than
-// depth-first order would; until then `best` is not yet tightened by it, which costs a few speculative node visits
-// (Aila & Laine's "speculative traversal", here without leaving the one-step-per-iteration loop). The closest hit is
-// the same: every candidate is still tested, nearer wins.
-template <bool COUNT>
-__global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceDualKernel(
+__global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceKernel(
     FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q, HitBuffer hb, ShardView sv, uint32_t cameraFrames, unsigned long long* counters,
     unsigned long long* rayTotals) {
     __shared__ uint2 sStack[kLdsStack + 1][kTraceThreads];  // (ref, entry distance), [entry][thread]; row kLdsStack = dummy for predicated-off pushes
@@ -967,137 +598,6 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
     }
 }
 
-#if OKRT_TAIL_DRAIN
-// ---- tail drain -----------------------------------------------------------------------------------------------------
-// One wave per continuation (TailView): the exported stack goes into LDS and is traversed up to 64 entries at a time,
-// one entry per lane — a node visit pushes its entered children back (positions by ballot + prefix popcount), a leaf tests
-// its triangles — until the stack is empty. Every lane keeps the best candidate it has seen itself; the wave shares the
-// smallest distance for culling and the final winner is the candidate closerHit ranks first, so the result is the one
-// the sequential kernels compute. The number of entries taken per round shrinks as the stack fills, down to one (plain
-// depth-first, bounded by 3 * depth + 4), so kDrainStack entries always suffice (checked on the host).
-__global__ __launch_bounds__(64) void drainKernel(FastView fv, RayQueue q, HitBuffer hb, TailView tv, uint32_t maxDepth) {
-    __shared__ uint2 sh[kDrainStack];
-    const uint32_t lane = threadIdx.x;
-    const TailConst tc = *tv.tc;
-    uint32_t* cont = tv.ctr + kShards * kCursorStride;
-    // (everything that steers the loops is wave-uniform and kept in SGPRs by readfirstlane: no divergent control flow around them)
-    const uint32_t total = __builtin_amdgcn_readfirstlane(min(__hip_atomic_load(&cont[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tc.capHeaders));
-    const uint32_t roomLimit = kDrainStack - 3u * maxDepth - 8u;  // beyond this only one entry is taken per round
-    for (uint32_t guard = 0; guard <= tc.capHeaders; ++guard) {  // (at most one pass per header for a single wave)
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&cont[2 * kCursorStride], 1u);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= total) break;
-        const uint4 h0 = tc.headers[2 * (size_t)c], h1 = tc.headers[2 * (size_t)c + 1];
-        const uint32_t rayIdx = __builtin_amdgcn_readfirstlane(h0.x), count = __builtin_amdgcn_readfirstlane(h1.w);
-        if (rayIdx == kInvalid || count == 0u) continue;
-        const float4 A = ldStream(&q.a[rayIdx]), B = ldStream(&q.b[rayIdx]);
-        const V3 ro = mk(A.x, A.y, A.z);
-        const V3 rdir = normalize(mk(A.w, B.x, B.y));
-        V3 iq = rcp3(rdir);
-        iq = mk(fminf(fmaxf(iq.x, -1e30f), 1e30f), fminf(fmaxf(iq.y, -1e30f), 1e30f), fminf(fmaxf(iq.z, -1e30f), 1e30f));
-        __syncthreads();  // (one wave per block: orders the previous continuation's reads of `sh` before these writes)
-        for (uint32_t k = lane; k < count && k < kDrainStack; k += 64) sh[k] = tc.entries[h1.z + k];
-        __syncthreads();
-        uint32_t sp = min(count, kDrainStack);                 // wave-uniform
-        float cull = __uint_as_float(h0.y);                    // smallest distance anybody has found: box culling
-        float best = lane == 0 ? cull : kFltMax;               // this lane's own candidate (lane 0 carries the exported one)
-        float hbu = __uint_as_float(h0.z), hbv = __uint_as_float(h0.w);
-        uint32_t hitIdx = lane == 0 ? h1.x : kInvalid, hitTri = lane == 0 ? h1.y : kInvalid;
-        uint32_t rounds = 0;
-        while (sp > 0 && ++rounds < 4096u) {  // (the bound is never reached on a valid tree: an exit every wave reaches whatever the tables hold)
-            sp = __builtin_amdgcn_readfirstlane(sp);
-            uint32_t take = min(sp, 64u);
-            if (sp + 3u * take > roomLimit) take = sp < roomLimit ? max((roomLimit - sp) / 3u, 1u) : 1u;
-            take = min(take, sp);
-            uint2 e = make_uint2(kDone, 0u);
-            if (lane < take) e = sh[sp - 1u - lane];
-            sp -= take;
-            __syncthreads();
-            const bool alive = lane < take && __uint_as_float(e.y) < cull;
-            const bool isNode = alive && !(e.x & kLeafBit);
-            float tn[4] = {kFltMax, kFltMax, kFltMax, kFltMax};
-            uint32_t ch[4] = {kDone, kDone, kDone, kDone};
-            if (isNode) {
-                const uint4* p = fv.nodes + (size_t)e.x * 4;
-                const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
-                ch[0] = n1.x; ch[1] = n1.y; ch[2] = n1.z; ch[3] = n1.w;
-                const float Ax = __uint_as_float((n0.w & 255u) << 23) * iq.x, Bx = (__uint_as_float(n0.x) - ro.x) * iq.x;
-                const float Ay = __uint_as_float(((n0.w >> 8) & 255u) << 23) * iq.y, By = (__uint_as_float(n0.y) - ro.y) * iq.y;
-                const float Az = __uint_as_float(((n0.w >> 16) & 255u) << 23) * iq.z, Bz = (__uint_as_float(n0.z) - ro.z) * iq.z;
-                const uint32_t nearX = iq.x >= 0.f ? n2.x : n3.x, farX = iq.x >= 0.f ? n3.x : n2.x;
-                const uint32_t nearY = iq.y >= 0.f ? n2.y : n3.y, farY = iq.y >= 0.f ? n3.y : n2.y;
-                const uint32_t nearZ = iq.z >= 0.f ? n2.z : n3.z, farZ = iq.z >= 0.f ? n3.z : n2.z;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
-                                              fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
-                    const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
-                                             fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
-                    const bool hit = tfar >= tnear && tfar > 0.f && tnear < cull && ch[k] != kEmptyRef;
-                    tn[k] = hit ? tnear : kFltMax;
-                }
-            } else if (alive) {  // a leaf: all of its triangles
-                const uint32_t first = e.x & 0x07FFFFFFu, cnt = ((e.x >> 27) & 15u) + 1u;
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    const uint4* p = (const uint4*)fv.tris + (size_t)(first + j) * 3;
-                    const uint4 d0 = p[0], d1 = p[1], d2 = p[2];
-                    float bu = 0.f, bv = 0.f;
-                    const float t = rayAndTriangleEdges(ro, rdir, mk(__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)),
-                                                        mk(__uint_as_float(d1.x), __uint_as_float(d1.y), __uint_as_float(d1.z)),
-                                                        mk(__uint_as_float(d2.x), __uint_as_float(d2.y), __uint_as_float(d2.z)), bu, bv);
-                    if (t > 0.f) {
-                        const float d = length(rdir * t);
-                        if (closerHit(d, d0.w, d1.w, best, hitTri, hitIdx)) {
-                            best = d;
-                            hbu = bu;
-                            hbv = bv;
-                            hitTri = d0.w;
-                            hitIdx = d1.w;
-                        }
-                    }
-                }
-            }
-            // entered children go back on the shared stack: child slot k of every lane, slot after slot
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool push = tn[k] < kFltMax;
-                const unsigned long long m = __ballot(push);
-                if (push) {
-                    const uint32_t pos = sp + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < kDrainStack) sh[pos] = make_uint2(ch[k], __float_as_uint(tn[k]));
-                }
-                sp = min(sp + (uint32_t)__popcll(m), kDrainStack);
-            }
-            float m = best;  // share the smallest distance found so far
-            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-            cull = fminf(cull, m);
-            __syncthreads();
-        }
-        // the winner: smallest distance, then closerHit's order (sphere first, then smaller triangle, then smaller instance)
-        float m = best;
-        for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-        const bool cand = best == m && m < kFltMax;
-        const uint32_t kt = cand ? hitTri + 1u : 0xFFFFFFFFu;  // kInvalid (a sphere hit) wraps to 0: ranks first
-        uint32_t mt = kt;
-        for (int off = 32; off > 0; off >>= 1) mt = min(mt, (uint32_t)__shfl_xor((int)mt, off, 64));
-        const bool cand2 = cand && kt == mt;
-        const uint32_t ki = cand2 ? hitIdx : 0xFFFFFFFFu;
-        uint32_t mi = ki;
-        for (int off = 32; off > 0; off >>= 1) mi = min(mi, (uint32_t)__shfl_xor((int)mi, off, 64));
-        const unsigned long long win = __ballot(cand2 && ki == mi);
-        if (win == 0ull) {  // nothing was hit at all
-            if (lane == 0) {
-                stStream(&hb.h[rayIdx], make_float4(kFltMax, 0.f, 0.f, __uint_as_float(kInvalid)));
-                stStream(&hb.tri[rayIdx], kInvalid);
-            }
-        } else if (lane == (uint32_t)__ffsll((long long)win) - 1u) {
-            stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
-            stStream(&hb.tri[rayIdx], hitTri);
-        }
-    }
-}
-#endif  // OKRT_TAIL_DRAIN
 
 // Known-answer probe (okrt_debug_kat, CLOSEST_HIT_FAST): one thread per ray walks the structure with a private stack —
 // the same node decoding, slab arithmetic, triangle test and hit-distance formula as the trace kernels, none of their
@@ -1176,25 +676,10 @@ __global__ __launch_bounds__(64) void fastKatKernel(const uint4* __restrict__ no
 }  // namespace
 
 void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
-                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals,
-                 const TailView& tv) {
+                 RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals) {
     const dim3 tb(kTraceThreads);
-    static const bool dual = !getenv("OKRT_FAST_DUAL") || atoi(getenv("OKRT_FAST_DUAL")) != 0;
-    if (dual && !tv.ctr) {
-        if (count) hipLaunchKernelGGL((traceDualKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
-        else hipLaunchKernelGGL((traceDualKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
-        return;
-    }
-    if (count) hipLaunchKernelGGL((traceKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, tv);
-    else hipLaunchKernelGGL((traceKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals, tv);
-}
-
-void launchDrain(dim3 grid, hipStream_t stream, const FastView& fv, RayQueue q, HitBuffer hb, const TailView& tv, uint32_t maxDepth) {
-#if OKRT_TAIL_DRAIN
-    hipLaunchKernelGGL(drainKernel, grid, dim3(64), 0, stream, fv, q, hb, tv, maxDepth);
-#else
-    (void)grid; (void)stream; (void)fv; (void)q; (void)hb; (void)tv; (void)maxDepth;
-#endif
+    if (count) hipLaunchKernelGGL((traceKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+    else hipLaunchKernelGGL((traceKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
 }
 
 void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,

@@ -474,7 +474,7 @@ def test_two_launch_sets_in_flight_are_bit_identical_to_one_at_a_time():
         rt.setDOF(0.4, 10.0)
         for _ in range(3):
             rt.renderFrames(16)
-        snaps.append(rt.ctx.peek_result()[0].copy() if False else rt.ctx.read_result().copy())
+        snaps.append(rt.ctx.read_result().copy())
         rt.resetAccumulation()
         rt.renderFrames(3)
         rt.render()
@@ -489,7 +489,9 @@ def test_two_launch_sets_in_flight_are_bit_identical_to_one_at_a_time():
         rt.close()
         return snaps
 
-    a, b = run(1), run(0)
+    a, b = run(32), run(0)  # every set of up to 32 frames pipelined / none
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True) if isinstance(x, np.ndarray) and x.dtype.kind == "f" else np.array_equal(x, y)
     assert (a[3][..., 3] == 17).all()
+    c = run(4)  # the default
+    assert np.array_equal(c[3], b[3], equal_nan=True) and np.array_equal(c[4], b[4])
