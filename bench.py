@@ -193,7 +193,7 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
     mb = args.max_bounces
     kernels = []
 
-    def add(name, ms_sum, alg_frame, l2_frame, once=0):
+    def add(name, ms_sum, alg_frame, l2_frame, once=0, stream_frame=0):
         if ms_sum <= 0:
             return
         launch_ms = ms_sum / launches
@@ -201,6 +201,9 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         l2 = l2_frame / per_gpu * frames_per_launch
         kernels.append({"kernel": name, "launch_ms": round(launch_ms, 4), "ms_per_frame": round(launch_ms / frames_per_launch, 5),
                         "algorithmic_bytes_per_launch": int(alg), "algorithmic_gbs": round(alg / (launch_ms * 1e-3) / 1e9, 1),
+                        # the part of the reads that is a coalesced 16-B-per-lane stream (queue entries, hit records, radiance slots):
+                        # the only pattern FETCH_SIZE under-counts (x2, profiles/r03_pmc_calibration.txt); tools/pmc_traffic.py adds it back
+                        "stream_read_bytes_per_launch": int(stream_frame / per_gpu * frames_per_launch),
                         "algorithmic_frac": round(alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "l2_request_bytes_per_launch": int(l2), "l2_frac": round(l2 / (launch_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)})
 
@@ -210,17 +213,19 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         cam_alg = 56 * cam_surv + slot * max(pixels - cam_surv, 0) + 64 * cam_hits + 16 * cam_taps + 16 * cam_env
         cam_l2 = (64 * cam_nodes + 48 * cam_tris) / 64 + cam_alg
         add("tracePacketKernel<FUSED> (camera segment: generate + packet traversal + shade + append)", interval_ms[0] + interval_ms[1], cam_alg, cam_l2,
-            structure_bytes)
+            structure_bytes, 0)
         if mb >= 1 and len(interval_ms) >= 4:
             tr = sum(interval_ms[2::2])
             sh = sum(interval_ms[3::2])
             # traceKernel: 32 B ray read + 20 B hit record write per ray; per-lane gathers of 64 B per node visit, 48 B per triangle test
-            add("traceKernel (bounce-ray traversal)", tr, 52 * bounce_rays, 64 * b_nodes + 48 * b_tris + 52 * bounce_rays, structure_bytes * mb)
+            add("traceKernel (bounce-ray traversal)", tr, 52 * bounce_rays, 64 * b_nodes + 48 * b_tris + 52 * bounce_rays, structure_bytes * mb, 32 * bounce_rays)
             later_surv = max(bounce_rays - cam_surv, 0)  # rays of segments 2..: appended by the later shading kernels
             sh_alg = (56 + 20) * bounce_rays + 64 * later_hits + 16 * later_taps + 16 * later_env + slot * max(bounce_rays - later_surv, 0) + 56 * later_surv
+            sh_stream = (56 + 20) * bounce_rays
             if frames_per_launch > 1:
                 sh_alg += (16 * frames_per_launch + 36) * pixels / frames_per_launch  # accumulateKernel: all slots once + accum RMW + resolve
-            add("shadeKernel<NEXT> + accumulateKernel (later segments: fetch, lights, BSDF, frame-slot accumulation)", sh, sh_alg, sh_alg)
+                sh_stream += (16 * frames_per_launch + 16) * pixels / frames_per_launch
+            add("shadeKernel<NEXT> + accumulateKernel (later segments: fetch, lights, BSDF, frame-slot accumulation)", sh, sh_alg, sh_alg, 0, sh_stream)
     elif interval_ms:
         add("renderReferenceOrder (reference-order megakernel)", interval_ms[0], ref_trav_bytes + ref_shade_bytes, ref_trav_bytes + ref_shade_bytes)
     if not kernels:
@@ -245,8 +250,11 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         "bound": "hbm", "kernel": head["kernel"], "launch_ms": head["launch_ms"], "frames_per_launch": frames_per_launch,
         "launches_timed": launches,
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "frac_basis": "measured HBM-side bytes (traffic) / live launch time / peak" if measured else "algorithmic bytes (lower bound of HBM traffic) / live launch time / peak",
+        "frac_basis": ("measured fabric-side bytes (traffic) / live launch time / peak; counters calibrated per access pattern, " + (pmc[1].get("calibration") or "uncalibrated")) if measured
+                      else "algorithmic bytes (lower bound of HBM traffic) / live launch time / peak",
         "traffic": traffic, "traffic_stale": not measured,
+        "traffic_kind": "bytes between L2 and the fabric (Infinity-Cache hits included: an upper bound of HBM bytes for a working set that fits its 256 MiB): "
+                        "FETCH_SIZE + half of the coalesced 16-B-per-lane stream reads (the one pattern it counts at half) + WRITE_SIZE" if measured else None,
         "traffic_source": pmc[0] if pmc else why,
         "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "algorithmic_frac": head["algorithmic_frac"],
         "l2_frac": head["l2_frac"], "l2_hit_pct": l2_hit, "valu_lane_util": lane_util,
@@ -259,8 +267,9 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         # for these rays over the traversal time. Far above 1: it measures the work the derived structure avoids, not a bandwidth.
         "reference_work_ratio": round(ref_trav_bytes / per_gpu / max(trace_ms_frame * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 2),
         "reference_algorithmic_bytes_per_ray": round(ref_trav_bytes / max(ref_c["segments"], 1), 1),
-        "note": "frac <= 1 by construction. The traversal kernels are latency-bound (dependent gathers served by L2 / Infinity Cache: the structure is "
-                "cache-resident), so their HBM fraction is low; the later-segment shading kernels are the HBM-bound part (kernels[].algorithmic_frac).",
+        "note": "frac <= 1 by construction. The traversal kernels are VALU-issue / latency bound (dependent gathers served by L2 and the Infinity Cache: the "
+                "structure is cache-resident), so their fabric fraction is low; the later-segment shading kernels move the most bytes per second "
+                "(kernels[].traffic_frac), a fabric / Infinity-Cache rate on this working set, not proven HBM.",
     }
 
 

@@ -51,6 +51,9 @@ struct okrt_ctx {
     bool fastDirty = true;
     bool fastGeometryDirty = true;  // t0 / t2 changed since the last build (device builder's leaf-range cache)
     uint32_t builder = 0;           // OKRT_OPT_BUILDER
+    // quirk Q3: the fast default renders shrunk instances differently from the reference; said once through
+    // okrt_last_error unless the host has looked at okrt_get_build_info().flags itself
+    bool buildFlagsRead = false, shrunkWarningDue = false;
     // Deferred okrt_render calls (OKRT_OPT_DEFER): consecutive frames of an unchanged scene wait here and are traced by
     // one launch set (renderImpl with frames > 1); anything that observes or changes state flushes them first.
     uint32_t pending = 0, deferMax = 16;
@@ -557,6 +560,7 @@ static okrt_status checkRenderArgs(okrt_ctx* c, const okrt_render_data* rd) {
 }
 static okrt_status ensureTables(okrt_ctx* c);
 static okrt_status ensureFast(okrt_ctx* c);
+static void warnShrunkInstancesOnce(okrt_ctx* c);
 
 // One frame (RayTracer::render, RayTracer.cpp:219-260). With OKRT_OPT_DEFER (default) a frame that continues the
 // progressive accumulation of an unchanged scene is not launched at once: it joins the pending frames and is traced
@@ -575,6 +579,7 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
     if (s != OKRT_OK) return s;
     OKRT_HIP(c, hipSetDevice(c->device));
     if ((s = ensureTables(c)) != OKRT_OK || (s = ensureFast(c)) != OKRT_OK) return s;
+    warnShrunkInstancesOnce(c);
     if (c->pending) {
         okrt_render_data expect = c->pendingRd;
         expect.numAccumulationFrames += c->pending;  // the host's pre-increment per frame (RayTracer.cpp:489)
@@ -623,7 +628,18 @@ static okrt_status ensureFast(okrt_ctx* c) {
     if (!fastBuild(&c->fast, in, dev, c->builder, c->stream, msg)) return fail(c, OKRT_ERR_DEVICE, "fast structure: " + msg);
     c->fastDirty = false;
     c->fastGeometryDirty = false;
+    c->shrunkWarningDue = (instanceFlags(c) & OKRT_BUILD_FLAG_SHRUNK_INSTANCES) != 0;
     return OKRT_OK;
+}
+
+// The status stays OKRT_OK; the text is there for a host that logs okrt_last_error after its first frame.
+static void warnShrunkInstancesOnce(okrt_ctx* c) {
+    if (!c->shrunkWarningDue) return;
+    c->shrunkWarningDue = false;
+    if (c->buildFlagsRead) return;
+    c->err = "warning: an instance matrix shrinks its mesh (OKRT_BUILD_FLAG_SHRUNK_INSTANCES): the reference drops geometry there (its BVH cull "
+             "compares a local-space box distance with the world-space best hit, RaytracerCS.hlsl:285 vs :311-318); OKRT_TRAVERSAL_FAST renders the true "
+             "closest hit instead. Select OKRT_TRAVERSAL_REFERENCE to reproduce the reference's picture exactly.";
 }
 
 okrt_status okrt_commit(okrt_ctx* c) {
@@ -646,6 +662,7 @@ okrt_status okrt_get_build_info(okrt_ctx* c, okrt_build_info* out) {
     out->device_ms = bi.deviceMs;
     out->wall_ms = bi.wallMs;
     out->flags = instanceFlags(c);
+    c->buildFlagsRead = true;
     return OKRT_OK;
 }
 
@@ -674,6 +691,7 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
     if (!referenceOrder) {
         okrt_status fs = ensureFast(c);
         if (fs != OKRT_OK) return fs;
+        warnShrunkInstancesOnce(c);
     }
     // OKRT_OPT_TIMING: the launch set records into the ring's next slot; the slot is only claimed (ringNext / ringCount
     // advance) once the launches succeeded, so a refused or failed attempt leaves the ring as it was

@@ -206,7 +206,11 @@ int okrt_abi_version(void);
 okrt_status okrt_device_count(int* out_count);
 okrt_status okrt_create(int device, okrt_ctx** out_ctx);
 okrt_status okrt_destroy(okrt_ctx* ctx);
-const char* okrt_last_error(const okrt_ctx* ctx); /* never NULL; "" when no error; ctx == NULL: why the last okrt_create failed */
+/* never NULL; "" when nothing was reported; ctx == NULL: why the last okrt_create failed. Besides the message of the last
+ * failed call it carries ONE kind of warning with status OKRT_OK (text starts with "warning:"): the first fast-traversal
+ * render after a build whose instance table has OKRT_BUILD_FLAG_SHRUNK_INSTANCES, unless the host has called
+ * okrt_get_build_info (see OKRT_OPT_TRAVERSAL) — the one place where the default picture knowingly differs from the reference's. */
+const char* okrt_last_error(const okrt_ctx* ctx);
 
 /* ---- scene upload (the Scene->Graphics interface) ------------------------------------------ */
 /* Replace a whole table. `elem_bytes` must equal the slot's reference stride. count==0 or

@@ -6,7 +6,10 @@
 Four separate passes (counters never share a run with --stats; FETCH_SIZE and WRITE_SIZE do not fit one pass:
 MI355X_MICROARCH.md "rocprofv3 PMC slots"):
   1. --kernel-trace --stats                     per-kernel launch durations (must agree with bench.py's HIP-event times)
-  2. --pmc FETCH_SIZE                           L2 -> fabric read bytes (KiB; x2 on gfx950 for 16-B-per-lane reads: upper bound)
+  2. --pmc FETCH_SIZE                           L2 -> fabric read requests x 64 B (KiB). Calibrated against known bytes per access pattern
+                                                (tools/pmc_calibrate.py -> profiles/r03_pmc_calibration.txt): exact for 64-byte gathers, 48-byte
+                                                records and texel taps (the over-fetch it shows is real 64-byte granularity), HALF for coalesced
+                                                16-B-per-lane streams (128-byte requests tallied at 64) -> half of the kernel's stream reads is added back
   3. --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum  fabric write bytes (KiB, exact), L2 hit rate
   4. --pmc SQ_* (8 slots)                       VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), wait shares
 Every bench run uses --steps F --warmup F --frames-per-launch F, so every launch of the non-counting kernel variants
@@ -99,8 +102,15 @@ def main():
         per_set = 1
         fetch, write = avg.get("FETCH_SIZE", 0.0) * 1024.0, avg.get("WRITE_SIZE", 0.0) * 1024.0
         hit, miss = avg.get("TCC_HIT_sum", 0.0), avg.get("TCC_MISS_sum", 0.0)
+        # the kernel's coalesced 16-B-per-lane stream reads (bench.py knows them from the ray / pixel counts): counted at half
+        stream = 0.0
+        for bk in ((bench_lines.get("stats") or {}).get("roofline") or {}).get("kernels", []):
+            if bk["kernel"].split(" ")[0].split("<")[0] == fam or (fam == "accumulateKernel" and False):
+                stream = float(bk.get("stream_read_bytes_per_launch", 0))
+        add_back = min(stream, 2.0 * fetch) / 2.0
         k = {"launches_seen": len(dur.get(fam, [])), "launch_ms": round(sum(dur[fam]) / len(dur[fam]), 4) if dur.get(fam) else None,
-             "fetch_bytes_raw": fetch * per_set, "write_bytes": write * per_set, "hbm_bytes_per_launch": (2.0 * fetch + write) * per_set,
+             "fetch_bytes_raw": fetch * per_set, "write_bytes": write * per_set, "stream_read_bytes": stream, "stream_add_back_bytes": add_back,
+             "hbm_bytes_per_launch": (fetch + add_back + write) * per_set,
              "l2_hit_pct": round(100.0 * hit / (hit + miss), 2) if hit + miss else None}
         if avg.get("SQ_ACTIVE_INST_VALU"):
             k["valu_lane_util"] = round(avg["SQ_THREAD_CYCLES_VALU"] / (64.0 * avg["SQ_ACTIVE_INST_VALU"]), 4)
@@ -117,20 +127,22 @@ def main():
         "workload": args.workload, "frames_per_launch": args.frames, "source_sha": bench.kernel_source_sha(),
         "command": "rocprofv3 <pass flags> --output-format csv -d <dir> -- " + " ".join(["python3", "bench.py"] + cmd[2:]),
         "passes": {n: "rocprofv3 " + " ".join(f) for n, f in PASSES},
-        "definition": "hbm_bytes_per_launch = 2 * FETCH_SIZE * 1024 (gfx950 counts a 128-B request as 64 B; an upper bound for the traversal "
-                      "kernels' 16-B gathers) + WRITE_SIZE * 1024, averaged over the launches of the non-counting kernel variants, each of which "
-                      "traces `frames_per_launch` frames",
+        "calibration": "profiles/r03_pmc_calibration.json",
+        "definition": "hbm_bytes_per_launch = fabric-side bytes = FETCH_SIZE * 1024 (exact for this code's 64-byte gathers, 48-byte records and texel taps) "
+                      "+ half of the kernel's coalesced 16-B-per-lane stream reads (the one pattern gfx950 tallies at half: 128-byte requests counted as 64) "
+                      "+ WRITE_SIZE * 1024 (exact; scattered 16 + 4-byte stores really move a 32-byte sector each), averaged over the launches of the "
+                      "non-counting kernel variants, each of which traces `frames_per_launch` frames. Infinity-Cache hits are included.",
         "kernels": kernels,
         "bench_line_under_stats": bench_lines.get("stats"),
     }
     path = os.path.join(args.out, f"pmc_{tag}.json")
     json.dump(out, open(path, "w"), indent=1)
     lines = [f"# {out['command']}", f"# source_sha {out['source_sha']}  frames per launch {args.frames}",
-             f"{'kernel':24s} {'launches':>8s} {'launch_ms':>10s} {'FETCHx2 MiB':>12s} {'WRITE MiB':>10s} {'HBM GB/s':>9s} {'frac':>6s} {'L2hit%':>7s} {'lanes':>6s}"]
+             f"{'kernel':24s} {'launches':>8s} {'launch_ms':>10s} {'FETCH MiB':>10s} {'+stream/2':>10s} {'WRITE MiB':>10s} {'fabric GB/s':>11s} {'frac':>6s} {'L2hit%':>7s} {'lanes':>6s}"]
     for fam, k in kernels.items():
         ms = k["launch_ms"] or 0.0
         gbs = k["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 if ms else 0.0
-        lines.append(f"{fam:24s} {k['launches_seen']:8d} {ms:10.3f} {2 * k['fetch_bytes_raw'] / 2**20:12.1f} {k['write_bytes'] / 2**20:10.1f} {gbs:9.1f} "
+        lines.append(f"{fam:24s} {k['launches_seen']:8d} {ms:10.3f} {k['fetch_bytes_raw'] / 2**20:10.1f} {k['stream_add_back_bytes'] / 2**20:10.1f} {k['write_bytes'] / 2**20:10.1f} {gbs:11.1f} "
                      f"{gbs / 8000.0:6.3f} {k['l2_hit_pct'] if k['l2_hit_pct'] is not None else 0:7.1f} {k.get('valu_lane_util', 0) or 0:6.3f}")
     for f in glob.glob(os.path.join(args.out, f"{tag}_stats", "*", "*_kernel_stats.csv")):
         lines.append("")
