@@ -1,6 +1,7 @@
 # Maintainer build without Python (python -c "import __graft_entry__ as g; g.build()" does the same, incrementally).
 #   make            libokrt.so (HIP, gfx950), libokrt_host.so (C++ host layer), examples/headless_host, examples/headless_host_mgpu
 #   make oracle     the CPU checker used by tests/ (and the compiled reference pieces when /root/reference exists)
+#   make asan       ASan + UBSan builds of the host layer and the checker, and the CPU test suite run against them
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 PKG      := gpu-raytracer_amd
@@ -35,7 +36,17 @@ oracle:
 	$(MAKE) -C oracle all
 	@if [ -d /root/reference/source ]; then $(MAKE) -C oracle ref; fi
 
+# CPU side under AddressSanitizer + UndefinedBehaviorSanitizer: the C++ host layer (file parsers, PNG encoder,
+# BVH / octree builders) and the CPU checker, then the whole CPU test suite against those builds. Nothing here touches a GPU.
+SAN := -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer
+asan:
+	$(CXX) $(filter-out -O2,$(CXXFLAGS)) $(SAN) -shared -o $(PKG)/libokrt_host_asan.so $(HOST_SRC)
+	$(CXX) -std=c++17 -fPIC -mfma -ffp-contract=off -fno-fast-math -pthread $(SAN) -shared -o oracle/liboracle_asan.so oracle/okrt_oracle.cpp
+	LD_PRELOAD="$$($(CXX) -print-file-name=libasan.so) $$($(CXX) -print-file-name=libstdc++.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
+	    OKRT_HOST_LIBRARY=$(abspath $(PKG)/libokrt_host_asan.so) OKRT_ORACLE_LIBRARY=$(abspath oracle/liboracle_asan.so) \
+	    python3 -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
+
 clean:
 	rm -rf $(PKG)/_build $(PKG)/libokrt.so $(PKG)/libokrt_host.so examples/headless_host examples/headless_host_mgpu
 
-.PHONY: all oracle clean
+.PHONY: all oracle asan clean

@@ -241,7 +241,8 @@ _host = None
 
 
 def host_library_path():
-    return os.path.join(_abi.PKG_DIR, "libokrt_host.so")
+    # OKRT_HOST_LIBRARY: developer override (the -fsanitize build of `make asan`)
+    return os.environ.get("OKRT_HOST_LIBRARY") or os.path.join(_abi.PKG_DIR, "libokrt_host.so")
 
 
 def host_library():

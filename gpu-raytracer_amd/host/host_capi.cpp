@@ -1,4 +1,5 @@
 // host_capi.cpp — flat C view of the host layer (okrt_host.h).
+#include <cstdio>
 #include <cstring>
 
 #include <string>
@@ -50,11 +51,20 @@ int okh_resources_import_obj(okh_resources* r, const char* filePath, float scale
         put(err);
         return -1;
     }
-    auto esc = [](const std::string& s) {
+    auto esc = [](const std::string& s) {  // always valid ASCII JSON: names come from files and need not be UTF-8
         std::string o;
-        for (char c : s) {
-            if (c == '"' || c == '\\') o += '\\';
-            o += c;
+        for (char ch : s) {
+            const unsigned char c = (unsigned char)ch;
+            if (c == '"' || c == '\\') {
+                o += '\\';
+                o += ch;
+            } else if (c < 0x20 || c >= 0x7F) {
+                char buf[8];
+                std::snprintf(buf, sizeof buf, "\\u%04x", (unsigned)c);  // (the byte value as a code point: a Latin-1 reading)
+                o += buf;
+            } else {
+                o += ch;
+            }
         }
         return o;
     };

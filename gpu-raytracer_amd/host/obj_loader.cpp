@@ -124,7 +124,7 @@ bool loadObjects(const std::string& filePath, std::vector<ObjObject>& outObjects
         } else if (key == "mtllib") {
             std::string name;
             in >> name;
-            loadMtl(dirOf(filePath) + name, mtl);
+            if (!name.empty()) loadMtl(dirOf(filePath) + name, mtl);  // (a bare "mtllib" would name the directory itself)
         } else if (key == "usemtl") {
             in >> material;
             cur = nullptr;

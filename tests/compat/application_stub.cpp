@@ -1,4 +1,4 @@
-// application_stub.cpp — a windowless stand-in for the reference's Application that makes the SAME calls, in the same
+// application_stub.cpp — a windowless test driver that makes the calls the reference's Application makes, in the same
 // order and with the same argument types, against the reference's own Scene / Entity / Components / ResourceManager
 // headers and the facade classes of gpu-raytracer_amd/host/compat (RayTracer, GPUStorage, RenderTexture, Okay::):
 //   Application::Application   Application.cpp:25-52    initiateDX11, m_target.initiate, loadMeshesAsEntities,
@@ -30,43 +30,47 @@
 #define STB_IMAGE_WRITE_IMPLEMENTATION
 #include "stb/stb_image_write.h"
 
-struct Application {
+// What a windowless host keeps alive between those calls (the members of the reference's Application that the compute
+// path touches; defaults from Application.h:30-34).
+struct HostState {
     RenderTexture m_target;
     ResourceManager m_resourceManager;
     Scene m_scene;
     RayTracer m_rayTracer;
-    uint32_t m_maxCullingTreeDepth = 2u, m_maxCullingTreeLeafEntities = 50u;  // Application.h:30-31
-    uint32_t m_maxBvhLeafTriangles = 5u, m_maxBvhDepth = 30u;                // Application.h:33-34
-
-    void loadMeshesAsEntities(std::string_view filePath, std::string_view texturesPath, float scale) {  // Application.cpp:131-152
-        std::vector<ResourceManager::ObjectDecription> objectDescriptions;
-        if (!m_resourceManager.importAssets(filePath, objectDescriptions, texturesPath, scale)) {
-            std::fprintf(stderr, "importAssets failed\n");
-            std::exit(1);
-        }
-        for (ResourceManager::ObjectDecription& objectDesc : objectDescriptions) {
-            Entity entity = m_scene.createEntity();
-            MeshComponent& meshComp = entity.addComponent<MeshComponent>();
-            meshComp.meshID = objectDesc.meshId;
-            meshComp.material.albedo.textureId = objectDesc.albedoTextureId;
-            meshComp.material.roughness.textureId = objectDesc.rougnessTextureId;
-            meshComp.material.metallic.textureId = objectDesc.metallicTextureId;
-            meshComp.material.specular.textureId = objectDesc.specularTextureId;
-            meshComp.material.normalMapIdx = objectDesc.normalTextureId;
-        }
-    }
-
-    void saveScreenshot(const char* path) {  // Application.cpp:661-674
-        ID3D11Texture2D* sourceBuffer = *m_target.getBuffer();
-        D3D11_TEXTURE2D_DESC desc{};
-        sourceBuffer->GetDesc(&desc);
-        void* textureData = nullptr;
-        Okay::getCPUTextureData(sourceBuffer, &textureData);
-        stbi_write_png(path, (int)desc.Width, (int)desc.Height, 4, textureData, desc.Width * 4);
-        unsigned char* bytes = (unsigned char*)textureData;
-        OKAY_DELETE_ARRAY(bytes);
-    }
+    uint32_t m_maxCullingTreeDepth = 2u, m_maxCullingTreeLeafEntities = 50u;
+    uint32_t m_maxBvhLeafTriangles = 5u, m_maxBvhDepth = 30u;
 };
+
+// The import step of Application.cpp:131-152 as this driver does it: every object the importer reports becomes one entity
+// carrying a MeshComponent whose material points at the object's five texture slots.
+static void entitiesFromFile(HostState& host, const char* objPath, float scale) {
+    std::vector<ResourceManager::ObjectDecription> found;
+    if (!host.m_resourceManager.importAssets(objPath, found, "", scale)) {
+        std::fprintf(stderr, "importAssets(%s) failed\n", objPath);
+        std::exit(1);
+    }
+    for (const ResourceManager::ObjectDecription& object : found) {
+        MeshComponent& mesh = host.m_scene.createEntity().addComponent<MeshComponent>();
+        Material& m = mesh.material;
+        m.normalMapIdx = object.normalTextureId;
+        m.specular.textureId = object.specularTextureId;
+        m.metallic.textureId = object.metallicTextureId;
+        m.roughness.textureId = object.rougnessTextureId;
+        m.albedo.textureId = object.albedoTextureId;
+        mesh.meshID = object.meshId;
+    }
+}
+
+// The read-back + encode of Application.cpp:661-674 (getCPUTextureData on the target's texture, stbi_write_png), sized
+// from the render texture itself.
+static bool writeTargetAsPng(const RenderTexture& target, const char* path) {
+    const glm::uvec2 size = target.getDimensions();
+    void* pixels = nullptr;
+    Okay::getCPUTextureData(*target.getBuffer(), &pixels);
+    const bool ok = pixels && stbi_write_png(path, (int)size.x, (int)size.y, 4, pixels, (int)size.x * 4) != 0;
+    delete[] static_cast<unsigned char*>(pixels);  // (what OKAY_DELETE_ARRAY does with the new[]'d block)
+    return ok;
+}
 
 int main(int argc, char** argv) {
     if (argc < 9) {
@@ -82,10 +86,10 @@ int main(int argc, char** argv) {
     const uint32_t width = (uint32_t)std::atoi(argv[5]), height = (uint32_t)std::atoi(argv[6]), frames = (uint32_t)std::atoi(argv[7]);
     const std::string env = std::string(argv[4]) == "-" ? "" : argv[4];
 
-    Application app;
+    HostState app;
     Okay::initiateDX11();                                                   // Application.cpp:25 (through Window / initiateImGui in the reference)
     app.m_target.initiate(width, height, TextureFormat::F_8X4);             // :28
-    app.loadMeshesAsEntities(argv[3], "", 1.f);                             // :44
+    entitiesFromFile(app, argv[3], 1.f);                                    // :44 (loadMeshesAsEntities)
     app.m_rayTracer.initiate(app.m_target, app.m_resourceManager, env);     // :48
     app.m_rayTracer.setScene(app.m_scene);                                  // :49
     if (!app.m_rayTracer.lastError().empty()) { std::fprintf(stderr, "initiate: %s\n", app.m_rayTracer.lastError().c_str()); return 1; }
@@ -113,7 +117,7 @@ int main(int argc, char** argv) {
     for (uint32_t f = 0; f < frames; ++f) app.m_rayTracer.render();
     if (!app.m_rayTracer.lastError().empty()) { std::fprintf(stderr, "render: %s\n", app.m_rayTracer.lastError().c_str()); return 1; }
 
-    app.saveScreenshot(argv[8]);
+    if (!writeTargetAsPng(app.m_target, argv[8])) { std::fprintf(stderr, "cannot write %s\n", argv[8]); return 1; }  // saveScreenshot, :661-674
     std::printf("frames %u meshes %zu triangles %u octree nodes %zu bvh nodes %zu\n", app.m_rayTracer.getNumAccumulationFrames(),
                 app.m_rayTracer.getMeshDescriptors().size(), app.m_rayTracer.getTrianglesPos().getCapacity(), app.m_rayTracer.getOctTreeNodes().size(),
                 app.m_rayTracer.getBvhTreeNodes().size());

@@ -42,7 +42,7 @@ class Oracle:
     """The CPU oracle (oracle/liboracle.so): test infrastructure only."""
 
     def __init__(self):
-        path = os.path.join(REPO, "oracle", "liboracle.so")
+        path = os.environ.get("OKRT_ORACLE_LIBRARY") or os.path.join(REPO, "oracle", "liboracle.so")  # (override: `make asan`)
         if not os.path.exists(path):
             import subprocess
             subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=True)
