@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                                           fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
                 const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
                                          fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
-                const bool hit = tfar >= tnear && tfar > 0.f && tnear < best && ch[k] != kEmptyRef;
+                const bool hit = tfar >= tnear && tfar > 0.f && tnear < best;  // (empty slots carry an inverted box: never entered)
                 tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
             }
             // sort the four (distance, child) pairs ascending: 5-comparator network, select-based (no branches)
@@ -459,16 +459,19 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 uint32_t key[4], ref[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    key[k] = 0xFFFFFFFFu;
+                    ref[k] = ch[k];
+                    if (ch[k] == kEmptyRef) continue;  // wave-uniform (the node sits in SGPRs): a scalar branch skips the whole child
                     const float tnear = fmaxf(fmaxf(fma_((float)((nearX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((nearY >> (8 * k)) & 255u), Ay, By)),
                                               fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
                     const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
                                              fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
                     const bool hit = tfar >= tnear && tfar > 0.f && tnear < best;
-                    const unsigned long long m = ch[k] != kEmptyRef ? __ballot(hit) : 0ull;
-                    // order key: entry distance (clamped to >= 0, so its bits sort as an integer) of the first lane entering
-                    const float t0 = __shfl(fmaxf(tnear, 0.f), m ? __ffsll((long long)m) - 1 : 0, 64);
-                    key[k] = m ? __float_as_uint(t0) : 0xFFFFFFFFu;
-                    ref[k] = ch[k];
+                    const unsigned long long m = __ballot(hit);
+                    // order key: entry distance (clamped to >= 0, so its bits sort as an integer) of the first lane entering.
+                    // The lane index is wave-uniform, so this is ONE v_readlane into an SGPR (a __shfl costs an LDS round
+                    // trip through ds_bpermute, four per node step) and the sort below runs on the scalar unit
+                    if (m) key[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(__builtin_amdgcn_fmed3f(tnear, 0.f, kFltMax)), __ffsll((long long)m) - 1);
                 }
 #define OKRT_USWAP(i, j)                                         \
     if (key[j] < key[i]) {                                       \
