@@ -172,3 +172,16 @@ def test_device_count_and_frame_size():
     ctx.set_tile(8, 1, 2)
     assert ctx.frame_size() == (40, 30) and ctx.tile_rows() == 14
     ctx.close()
+
+
+def test_rccl_is_bound_at_run_time_with_every_symbol_the_exchange_uses():
+    """What a 1-GPU box can say about the RCCL leg: librccl.so.1 loads on first use, every entry point the gather / reduce
+    call is found (okrt_comm_unique_id fails with the missing symbol's name otherwise), and ncclGetUniqueId hands out a
+    128-byte id. The sends / receives themselves need N GPUs."""
+    import ctypes
+    fns = abi.load_device_library()
+    a, b = (ctypes.c_uint8 * 128)(), (ctypes.c_uint8 * 128)()
+    assert fns.comm_unique_id(a) == 0, fns.comm_last_error(None)
+    assert fns.comm_unique_id(b) == 0
+    assert any(a) and bytes(a) != bytes(b)
+    assert fns.comm_unique_id(None) == -1
