@@ -245,11 +245,90 @@ struct Emitter {
         return kLeafBit | ((n.count - 1) << 27) | first;
     }
 
+    // ---- which BVH2 nodes become the children of a wide node -----------------------------------------------------------
+    // Greedy (rounds 1-2): open the inner child with the largest area until there are four. SAH-optimal (round 3, after
+    // Ylitie, Karras, Laine 2017, for 4-wide nodes): cost[n][i] = the cheapest way to represent BVH2 subtree n as a FOREST of
+    // at most i wide-node roots / leaves, with a wide node costing area x kWideNodeCost and a leaf area x triangles x
+    // kWideTriCost; cost[n][1] roots a wide node at n whose (at most four) children are the forests of its two halves.
+    static constexpr float kInfCost = 3.0e38f;
+    std::vector<float> cost;       // [node][i], i = 1..3 at [4 * node + i]
+    std::vector<uint8_t> choice;   // [4 * node + i]: i = 1: roots the left half gets (1..3); i > 1: 0 = as for i - 1, else roots for the left half
+    bool optimal = false;
+
+    void solve(int32_t root) {
+        static const float kWideNodeCost = getenv("OKRT_BUILD_WIDE_NODE_COST") ? (float)atof(getenv("OKRT_BUILD_WIDE_NODE_COST")) : 1.0f;
+        static const float kWideTriCost = getenv("OKRT_BUILD_WIDE_TRI_COST") ? (float)atof(getenv("OKRT_BUILD_WIDE_TRI_COST")) : 0.6f;
+        cost.assign(4 * b.nodes.size(), kInfCost);
+        choice.assign(4 * b.nodes.size(), 0);
+        // post-order without recursion: a node is finished when both children are
+        std::vector<std::pair<int32_t, bool>> stack{{root, false}};
+        while (!stack.empty()) {
+            const auto [n, expanded] = stack.back();
+            stack.pop_back();
+            const Node2& nd = b.nodes[n];
+            float* c = &cost[4 * (size_t)n];
+            uint8_t* ch = &choice[4 * (size_t)n];
+            if (nd.left < 0) {
+                c[1] = c[2] = c[3] = nd.box.area() * (float)nd.count * kWideTriCost;
+                continue;
+            }
+            if (!expanded) {
+                stack.push_back({n, true});
+                stack.push_back({nd.left, false});
+                stack.push_back({nd.right, false});
+                continue;
+            }
+            const float* l = &cost[4 * (size_t)nd.left];
+            const float* r = &cost[4 * (size_t)nd.right];
+            float best = kInfCost;
+            for (int i = 1; i <= 3; ++i) {  // a wide node here: i children from the left half, 4 - i from the right
+                const float v = l[i] + r[4 - i];
+                if (v < best) {
+                    best = v;
+                    ch[1] = (uint8_t)i;
+                }
+            }
+            c[1] = nd.box.area() * kWideNodeCost + best;
+            for (int i = 2; i <= 3; ++i) {  // a forest of at most i roots: no better than i - 1, or split between the halves
+                c[i] = c[i - 1];
+                ch[i] = 0;
+                for (int k = 1; k < i; ++k) {
+                    const float v = l[k] + r[i - k];
+                    if (v < c[i]) {
+                        c[i] = v;
+                        ch[i] = (uint8_t)k;
+                    }
+                }
+            }
+        }
+        optimal = true;
+    }
+    // the roots of the cheapest forest of at most i roots for subtree n
+    void forest(int32_t n, int i, int32_t* out, int& count) const {
+        const Node2& nd = b.nodes[n];
+        if (nd.left < 0 || i == 1) {
+            out[count++] = n;
+            return;
+        }
+        const uint8_t k = choice[4 * (size_t)n + i];
+        if (k == 0) forest(n, i - 1, out, count);
+        else {
+            forest(nd.left, k, out, count);
+            forest(nd.right, i - k, out, count);
+        }
+    }
+
     // Emits the Node4 for BVH2 node `root` at out.nodes[slot].
     void emitNode(uint32_t slot, int32_t root, uint32_t depth) {
         maxDepth = std::max(maxDepth, depth);
         int32_t kids[4] = {b.nodes[root].left, b.nodes[root].right, -1, -1};
         int n = 2;
+        if (optimal) {
+            n = 0;
+            const int k = choice[4 * (size_t)root + 1];
+            forest(b.nodes[root].left, k, kids, n);
+            forest(b.nodes[root].right, 4 - k, kids, n);
+        } else
         while (n < 4) {  // open the inner child with the largest area
             int pick = -1;
             float best = -1.f;
@@ -370,6 +449,8 @@ void buildFastHost(const FastInputs& in, FastHostScene& out) {
         out.maxDepth = 1;
         return;
     }
+    static const bool kOptimalCollapse = !getenv("OKRT_BUILD_COLLAPSE") || atoi(getenv("OKRT_BUILD_COLLAPSE")) != 0;  // 0 = greedy (rounds 1-2)
+    if (kOptimalCollapse) e.solve((int32_t)r);
     e.emitNode(0, (int32_t)r, 1);
     out.maxDepth = e.maxDepth;
 }

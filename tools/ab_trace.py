@@ -14,7 +14,10 @@ for wl in (sys.argv[1:] or ["sponza"]):
         c = ctx.counters(); ctx.set_option(abi.OPT_COUNTERS, 0); ctx.set_option(abi.OPT_MAX_BOUNCES, 1); return c
     full, cam = counted(1), counted(0)
     br = max(full["segments"] - full["pixels"], 1)
-    line = f"{wl}: bounce rays {br}, nodes/ray {(full['fast_nodes'] - cam['fast_nodes']) / br:.2f}, tris/ray {(full['fast_tris'] - cam['fast_tris']) / br:.2f} |"
+    tiles = max(cam["pixels"] / 64, 1)
+    bi = ctx.build_info()
+    line = (f"{wl}: {bi['num_nodes']} nodes depth {bi['max_depth']}, camera tile: {cam['fast_nodes'] / 64 / tiles:.2f} node steps {cam['fast_tris'] / 64 / tiles:.2f} tris; "
+            f"bounce rays {br}, nodes/ray {(full['fast_nodes'] - cam['fast_nodes']) / br:.2f}, tris/ray {(full['fast_tris'] - cam['fast_tris']) / br:.2f} |")
     rt.resetAccumulation()
     rt.renderFrames(64)
     for F in (64, 1):
