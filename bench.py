@@ -298,6 +298,9 @@ def main():
                     help="consecutive frames traced by one set of kernel launches (okrt_render_frames); 0 = auto")
     args = ap.parse_args()
 
+    # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails with
+    # "hipIpcGetMemHandle: invalid argument" (must be in the environment before the HIP runtime initialises)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     abi = importlib.import_module("gpu-raytracer_amd._abi")
     scenes = importlib.import_module("gpu-raytracer_amd.scenes")
     mgpu = importlib.import_module("gpu-raytracer_amd.mgpu")
