@@ -61,13 +61,15 @@ struct okrt_ctx {
     okrt_render_data pendingRd{};
     bool externalFramebuffers = false, externalStream = false;
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
-    // OKRT_OPT_PIPELINE: consecutive launch sets of a progressive accumulation alternate between two queue slots and two
-    // streams, so the next set's bulk fills the GPU while the previous set's last rays drain. Only the accumulation is
+    // OKRT_OPT_PIPELINE: consecutive launch sets of a progressive accumulation take turns on up to four queue slots, each with
+    // its own stream, so the next sets' bulk fills the GPU while the previous sets' last rays drain. Only the accumulation is
     // ordered between them (accumDone events). Every entry point but the render calls joins stream B back into `stream`.
-    bool pipelineOn = true, bActive = false, needSyncB = true, accumChain = false;
-    uint32_t pipelineMaxFrames = kPipelineDefaultFrames;  // launch sets up to this many frames alternate between the two slots
-    hipStream_t streamB = nullptr;
-    hipEvent_t accumDone[2] = {nullptr, nullptr}, evJoinA = nullptr, evJoinB = nullptr;
+    bool pipelineOn = true, accumChain = false;
+    bool sideActive[kPipelineSlots] = {}, sideNeedsSync[kPipelineSlots] = {};  // per side stream: work since the last join / main-stream work since it last ran
+    uint32_t pipelineMaxFrames = kPipelineDefaultFrames;  // launch sets up to this many frames take turns on the queue slots
+    uint32_t pipelineDepth = kPipelineSlots;              // how many of the slots are used (OKRT_PIPELINE_DEPTH in the environment: 2 ... 4)
+    hipStream_t side[kPipelineSlots] = {};  // side[0] is unused (slot 0 runs on `stream`)
+    hipEvent_t accumDone[kPipelineSlots] = {}, evJoinA = nullptr, evJoinB = nullptr;
     uint32_t pipeNext = 0, pipeLast = 0;
     // okrt_peek_result_rgba8: two device-side copies of the resolved picture, refreshed alternately at the end of every
     // launch set once a host has asked for one; the peek copies the newest finished one out on its own stream
@@ -118,14 +120,16 @@ okrt_status flushPending(okrt_ctx* c) {
     c->pending = 0;
     return renderBatched(c, &c->pendingRd, n, true);
 }
-// Everything launched on stream B so far is ordered before whatever follows on the context's main stream; the next
-// launch on B waits for the main stream in turn (uploads, resets, ... made there).
+// Everything launched on the side streams so far is ordered before whatever follows on the context's main stream; the
+// next launch on a side stream waits for the main stream in turn (uploads, resets, ... made there).
 okrt_status joinStreams(okrt_ctx* c) {
-    c->needSyncB = true;
-    if (!c->bActive) return OKRT_OK;
-    c->bActive = false;
-    if (hipSetDevice(c->device) != hipSuccess || hipEventRecord(c->evJoinB, c->streamB) != hipSuccess || hipStreamWaitEvent(c->stream, c->evJoinB, 0) != hipSuccess)
-        return fail(c, OKRT_ERR_DEVICE, "pipeline: joining the second stream failed");
+    for (uint32_t k = 1; k < kPipelineSlots; ++k) {
+        c->sideNeedsSync[k] = true;
+        if (!c->sideActive[k]) continue;
+        c->sideActive[k] = false;
+        if (hipSetDevice(c->device) != hipSuccess || hipEventRecord(c->evJoinB, c->side[k]) != hipSuccess || hipStreamWaitEvent(c->stream, c->evJoinB, 0) != hipSuccess)
+            return fail(c, OKRT_ERR_DEVICE, "pipeline: joining a side stream failed");
+    }
     return OKRT_OK;
 }
 // every entry point that observes or changes state: deferred frames executed, both streams joined
@@ -334,8 +338,14 @@ okrt_status okrt_create(int device, okrt_ctx** out) {
     c->stream = c->ownStream;
     hipEventCreate(&c->evBegin);
     hipEventCreate(&c->evEnd);
-    if (hipStreamCreateWithFlags(&c->streamB, hipStreamNonBlocking) != hipSuccess) c->streamB = nullptr, c->pipelineOn = false;
-    for (hipEvent_t* e : {&c->accumDone[0], &c->accumDone[1], &c->evJoinA, &c->evJoinB})
+    if (const char* d = getenv("OKRT_PIPELINE_DEPTH")) c->pipelineDepth = std::min<uint32_t>(std::max(atoi(d), 2), kPipelineSlots);
+    for (uint32_t k = 1; k < kPipelineSlots; ++k) {
+        c->sideNeedsSync[k] = true;
+        if (hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) != hipSuccess) c->side[k] = nullptr, c->pipelineOn = false;
+    }
+    for (uint32_t k = 0; k < kPipelineSlots; ++k)
+        if (hipEventCreateWithFlags(&c->accumDone[k], hipEventDisableTiming) != hipSuccess) c->pipelineOn = false;
+    for (hipEvent_t* e : {&c->evJoinA, &c->evJoinB})
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) c->pipelineOn = false;
     if ((e = hipMalloc(&c->counters.ptr, kNumCounters * sizeof(unsigned long long))) != hipSuccess) {
         g_createError = std::string("hipMalloc: ") + hipGetErrorString(e);
@@ -354,11 +364,14 @@ okrt_status okrt_destroy(okrt_ctx* c) {
     hipSetDevice(c->device);
     (void)joinStreams(c);
     hipStreamSynchronize(c->stream);
-    if (c->streamB) {
-        hipStreamSynchronize(c->streamB);
-        hipStreamDestroy(c->streamB);
-    }
-    for (hipEvent_t e : {c->accumDone[0], c->accumDone[1], c->evJoinA, c->evJoinB})
+    for (uint32_t k = 1; k < kPipelineSlots; ++k)
+        if (c->side[k]) {
+            hipStreamSynchronize(c->side[k]);
+            hipStreamDestroy(c->side[k]);
+        }
+    for (uint32_t k = 0; k < kPipelineSlots; ++k)
+        if (c->accumDone[k]) hipEventDestroy(c->accumDone[k]);
+    for (hipEvent_t e : {c->evJoinA, c->evJoinB})
         if (e) hipEventDestroy(e);
     for (Table& t : c->tables)
         if (t.dev.ptr) hipFree(t.dev.ptr);
@@ -732,12 +745,12 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
             order.frameSlots = true;
             order.after = c->accumChain ? c->accumDone[c->pipeLast] : nullptr;
             order.done = c->accumDone[order.slot];
-            if (order.slot == 1u) {
-                launchStream = c->streamB;
-                if (c->needSyncB) {  // uploads, resets, ... made on the main stream since B last ran
+            if (order.slot != 0u) {
+                launchStream = c->side[order.slot];
+                if (c->sideNeedsSync[order.slot]) {  // uploads, resets, ... made on the main stream since this side stream last ran
                     OKRT_HIP(c, hipEventRecord(c->evJoinA, c->stream));
-                    OKRT_HIP(c, hipStreamWaitEvent(c->streamB, c->evJoinA, 0));
-                    c->needSyncB = false;
+                    OKRT_HIP(c, hipStreamWaitEvent(launchStream, c->evJoinA, 0));
+                    c->sideNeedsSync[order.slot] = false;
                 }
             }
         } else {  // accumulates from inside its kernels, on the main stream: after everything B still has in flight
@@ -751,9 +764,9 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
                         "fast pipeline: " + msg);
         used = 2 * (c->maxBounces + 1) + 1;
         if (pipelined) {
-            c->bActive = c->bActive || order.slot == 1u;
+            if (order.slot != 0u) c->sideActive[order.slot] = true;
             c->pipeLast = order.slot;
-            c->pipeNext = order.slot ^ 1u;
+            c->pipeNext = (order.slot + 1u) % c->pipelineDepth;
             c->accumChain = true;
         } else {
             c->accumChain = false;  // (stream order on the main stream covers it)
@@ -894,7 +907,7 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             return OKRT_OK;
         case OKRT_OPT_PIPELINE:
             if (value < 0 || value > (int64_t)kPipelineMaxFrames) return fail(c, OKRT_ERR_INVALID_ARG, "pipeline: 0 (off) .. 32 frames per launch set");
-            c->pipelineOn = value != 0 && c->streamB != nullptr;
+            c->pipelineOn = value != 0 && c->side[1] != nullptr;
             if (value) c->pipelineMaxFrames = (uint32_t)value;
             return OKRT_OK;
         case OKRT_OPT_DEBUG_FAIL_ALLOC:

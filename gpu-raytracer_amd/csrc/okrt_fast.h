@@ -133,11 +133,11 @@ void fastDestroy(FastScene* scene);
 // their radiance lands in per-frame slots and is added to `accum` in frame order, so the result is bit-identical to
 // `frames` single-frame calls (frames > 1 requires accumulationEnabled == 1).
 enum class LaunchStatus { Ok, OutOfMemory /* queues do not fit (budget or allocator): retry with fewer frames */, Invalid, Device };
-// Two launch sets in flight (OKRT_OPT_PIPELINE): each uses its own queue slot and stream; what must stay ordered is the
+// Launch sets in flight together (OKRT_OPT_PIPELINE, up to kPipelineSlots): each uses its own queue slot and stream; what must stay ordered is the
 // accumulation, so a pipelined set keeps its radiance in frame slots (also for one frame) and adds them in ONE kernel
 // that waits for `after` (the previous set's accumulation) and signals `done`.
 struct LaunchOrder {
-    uint32_t slot = 0;         // which of the two queue sets
+    uint32_t slot = 0;         // which of the kPipelineSlots queue sets
     bool frameSlots = false;   // radiance slots + accumulateKernel even for a single frame
     hipEvent_t after = nullptr, done = nullptr;
 };
@@ -145,6 +145,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
                         uint32_t* result, unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events,
                         uint32_t frames, const LaunchOrder& order, std::string& err);
 constexpr uint32_t kMaxFramesPerLaunch = 64;
+constexpr uint32_t kPipelineSlots = 4;  // launch sets that may be in flight together (queue slots = streams)
 constexpr uint32_t kPipelineMaxFrames = 32, kPipelineDefaultFrames = 4;  // OKRT_OPT_PIPELINE: launch sets up to n frames alternate between the two queue slots
 
 }  // namespace okrt

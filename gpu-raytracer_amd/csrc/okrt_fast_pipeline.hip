@@ -84,8 +84,8 @@ struct FastScene {
     bool allIdentity = true;
     DeviceBuilder* builder = nullptr;  // device-side build scratch (okrt_fast_build_device.hip), made on first use
     FastBuildInfo info = {};
-    // pipeline state of a launch set, sized lazily for the tile. Two slots: consecutive launch sets of a progressive
-    // accumulation may be in flight together on two streams (okrt_context.hip, OKRT_OPT_PIPELINE), each with its own
+    // pipeline state of a launch set, sized lazily for the tile. kPipelineSlots slots: consecutive launch sets of a progressive
+    // accumulation may be in flight together, each on its own stream (okrt_context.hip, OKRT_OPT_PIPELINE), each with its own
     // queues, counters, spill slab and RenderData copy.
     struct LaunchSlot {
         size_t capacity = 0, capacityQ0 = 0;  // items queue 1 + the hit records / queue 0 are allocated for
@@ -98,7 +98,7 @@ struct FastScene {
         okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
         float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
         size_t radianceCap = 0;
-    } slot[2];
+    } slot[kPipelineSlots];
     uint32_t overflowCap = 0;  // entries per thread the spill slabs need for the current tree
     int traceBlocks = 0, cus = 0;
     size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
@@ -213,7 +213,7 @@ void fastDestroy(FastScene* fs) {
 LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
                         unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
                         const LaunchOrder& order, std::string& err) {
-    FastScene::LaunchSlot& ls = fs.slot[order.slot & 1u];
+    FastScene::LaunchSlot& ls = fs.slot[order.slot % kPipelineSlots];
     const uint32_t perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
     if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)perFrame * frames > 0x7FFFFFFFull) {
         err = "frames per launch out of range";

@@ -160,18 +160,19 @@ typedef enum okrt_option {
     /* Test hook: n > 0 = the n-th ray-queue allocation from now on fails as hipMalloc would when memory runs out (so that
      * the launch-set split on a REAL allocator failure can be tested); 0 = off. Process-wide. */
     OKRT_OPT_DEBUG_FAIL_ALLOC = 7,
-    /* n > 0 (default 4, at most 32) = two launch sets in flight: consecutive launch sets of at most n frames that continue
-     * a progressive accumulation (fast traversal, no debug mode, library-owned stream and framebuffers) alternate between
-     * two sets of ray queues and two HIP streams, so the next set's camera rays fill the GPU while the previous set's
-     * longest rays — a chain of dependent steps that no amount of parallelism shortens — are still draining. Only the
+    /* n > 0 (default 4, at most 32) = launch sets in flight together: consecutive launch sets of at most n frames that
+     * continue a progressive accumulation (fast traversal, no debug mode, library-owned stream and framebuffers) take turns
+     * on four sets of ray queues, each with its own HIP stream, so the next sets' camera rays fill the GPU while the previous
+     * sets' longest rays — a chain of dependent steps that no amount of parallelism shortens — are still draining. Only the
      * accumulation is ordered between the sets (each adds its frames in one kernel that waits for the previous set's), so
      * the framebuffers are bit-identical to one set at a time. Every entry point other than okrt_render /
-     * okrt_render_frames joins the two streams first: nothing else can observe the overlap. What it buys depends on how
-     * long the scene's longest rays are against a set's bulk (1080p, ms per frame, off -> on): one frame per set
-     * 0.96 -> 0.75 (Sponza-class), 1.96 -> 1.13 (871 k-triangle mesh), 0.77 -> 0.56 (glass scene); sets of 16:
-     * 0.557 -> 0.577, 0.340 -> 0.290, 0.208 -> 0.210 — two large persistent grids sharing the GPU cost more than the
-     * overlap returns unless the tail is long, hence the default of 4; a host with a tail-heavy scene sets 32.
-     * Footprint: the queues of TWO launch sets of up to n frames. 0 = one launch set at a time. */
+     * okrt_render_frames joins the streams first: nothing else can observe the overlap. What it buys depends on how long
+     * the scene's longest rays are against a set's bulk (1080p, ms per frame, off -> on): one frame per set 0.91 -> 0.66
+     * (Sponza-class), 1.88 -> 0.67 (871 k-triangle mesh); sets of 4: 0.64 -> 0.59, 0.66 -> 0.33; sets of 16:
+     * 0.52 -> 0.57, 0.32 -> 0.29 — large persistent grids sharing the GPU cost each other more than the overlap returns
+     * unless the tail is long, hence the default of 4; a host with a tail-heavy scene sets 32.
+     * Footprint: the queues of up to FOUR launch sets of up to n frames (default: 4 x 0.76 GB at 1080p). 0 = one launch
+     * set at a time. */
     OKRT_OPT_PIPELINE = 8
 } okrt_option;
 

@@ -1,4 +1,5 @@
-"""One okrt_render per frame (the reference's main loop): ms per frame with deferral off / 16, pipeline on / off.
+"""One okrt_render per frame (the reference's main loop): ms per frame at deferral 0 ... 16 and launch sets of 32, with launch
+sets in flight together (OKRT_OPT_PIPELINE; OKRT_PIPELINE_DEPTH=2..4 in the environment picks how many) and without.
 usage: python tools/percall_probe.py [workload ...]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.getcwd())
@@ -26,5 +27,5 @@ for wl in (sys.argv[1:] or ["sponza"]):
             for _ in range(256 // F): rt.renderFrames(F)
             ctx.synchronize()
             out.append(f"p{pipe} sets of {F}: {(time.perf_counter() - t) * 1e3 / 256:.4f}")
-    print(wl, "ms per frame |", " | ".join(out), flush=True)
+    print(wl, "depth", os.environ.get("OKRT_PIPELINE_DEPTH", "4"), "ms per frame |", " | ".join(out), flush=True)
     rt.close()
