@@ -57,6 +57,7 @@ struct okrt_ctx {
     // Deferred okrt_render calls (OKRT_OPT_DEFER): consecutive frames of an unchanged scene wait here and are traced by
     // one launch set (renderImpl with frames > 1); anything that observes or changes state flushes them first.
     uint32_t pending = 0, deferMax = 16;
+    bool deferReserved = false;  // the queues of a full deferred launch set are allocated (OOM belongs to the call that defers)
     uint32_t batchLimit = kMaxFramesPerLaunch;  // halved when the queues of a launch set do not fit in memory
     okrt_render_data pendingRd{};
     bool externalFramebuffers = false, externalStream = false;
@@ -199,6 +200,7 @@ okrt_status allocFramebuffers(okrt_ctx* c) {
     c->externalFramebuffers = false;  // okrt_resize / okrt_set_tile rebind to the library's own buffers (okrt.h: re-bind after them)
     c->frontValid[0] = c->frontValid[1] = false;  // pictures of another frame size
     c->launchedFrames = 0;
+    c->deferReserved = false;
     if (px) {
         OKRT_HIP(c, hipMemsetAsync(c->accum, 0, px * sizeof(float4), c->stream));
         OKRT_HIP(c, hipMemsetAsync(c->result, 0, px * 4, c->stream));
@@ -593,6 +595,22 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
     OKRT_HIP(c, hipSetDevice(c->device));
     if ((s = ensureTables(c)) != OKRT_OK || (s = ensureFast(c)) != OKRT_OK) return s;
     warnShrunkInstancesOnce(c);
+    if (!c->deferReserved && c->tile.rows && c->pending >= 1) {
+        // the host is looping (a second frame waits): what the deferred frames will need when they are finally launched is
+        // allocated NOW, so that an allocator refusal is reported inside the loop, by a call that defers, and not by whichever
+        // unrelated call happens to flush (smaller launch sets are tried first, like renderBatched does). A host that looks
+        // at every frame never gets here and keeps single-frame queues.
+        uint32_t n = std::min(c->deferMax, c->batchLimit);
+        std::string msg;
+        for (;;) {
+            const LaunchStatus ls = fastReserve(*c->fast, makeView(c), c->tile, n, 0u, n > 1, c->stream, msg);
+            if (ls == LaunchStatus::Ok) break;
+            if (ls != LaunchStatus::OutOfMemory || n == 1) return fail(c, ls == LaunchStatus::OutOfMemory ? OKRT_ERR_OOM : OKRT_ERR_DEVICE, "fast pipeline: " + msg);
+            n /= 2;
+        }
+        c->batchLimit = std::min(c->batchLimit, n);
+        c->deferReserved = true;
+    }
     if (c->pending) {
         okrt_render_data expect = c->pendingRd;
         expect.numAccumulationFrames += c->pending;  // the host's pre-increment per frame (RayTracer.cpp:489)
@@ -641,6 +659,7 @@ static okrt_status ensureFast(okrt_ctx* c) {
     if (!fastBuild(&c->fast, in, dev, c->builder, c->stream, msg)) return fail(c, OKRT_ERR_DEVICE, "fast structure: " + msg);
     c->fastDirty = false;
     c->fastGeometryDirty = false;
+    c->deferReserved = false;  // (the spill slab follows the tree depth)
     c->shrunkWarningDue = (instanceFlags(c) & OKRT_BUILD_FLAG_SHRUNK_INSTANCES) != 0;
     return OKRT_OK;
 }
@@ -894,16 +913,19 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
         case OKRT_OPT_MAX_BOUNCES:
             if (value < 0 || value > 64) return fail(c, OKRT_ERR_INVALID_ARG, "max_bounces: 0..64");
             c->maxBounces = (int)value;
+            c->deferReserved = false;  // (a third segment needs the second queue)
             return OKRT_OK;
         case OKRT_OPT_COUNTERS: c->countersOn = value != 0; return OKRT_OK;
         case OKRT_OPT_DEFER:
             if (value < 0 || value > (int64_t)kMaxFramesPerLaunch) return fail(c, OKRT_ERR_INVALID_ARG, "defer: 0 (off) .. 64 frames");
             c->deferMax = (uint32_t)value;
+            c->deferReserved = false;
             return OKRT_OK;
         case OKRT_OPT_QUEUE_MEMORY_MB:
             if (value < 0) return fail(c, OKRT_ERR_INVALID_ARG, "queue memory: MiB >= 0");
             fastSetQueueBudget(&c->fast, (size_t)value << 20);
             c->batchLimit = kMaxFramesPerLaunch;  // probe again from the top
+            c->deferReserved = false;
             return OKRT_OK;
         case OKRT_OPT_PIPELINE:
             if (value < 0 || value > (int64_t)kPipelineMaxFrames) return fail(c, OKRT_ERR_INVALID_ARG, "pipeline: 0 (off) .. 32 frames per launch set");

@@ -144,6 +144,9 @@ struct LaunchOrder {
 LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum,
                         uint32_t* result, unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events,
                         uint32_t frames, const LaunchOrder& order, std::string& err);
+// The device memory a launch set of `frames` frames will need on queue slot `slot`, allocated now (a deferred okrt_render
+// reserves what its launch set will use, so that an allocator refusal belongs to the call that caused it).
+LaunchStatus fastReserve(FastScene& fs, const SceneView& s, const TileView& t, uint32_t frames, uint32_t slot, bool frameSlots, hipStream_t stream, std::string& err);
 constexpr uint32_t kMaxFramesPerLaunch = 64;
 constexpr uint32_t kPipelineSlots = 4;  // launch sets that may be in flight together (queue slots = streams)
 constexpr uint32_t kPipelineMaxFrames = 32, kPipelineDefaultFrames = 4;  // OKRT_OPT_PIPELINE: launch sets up to n frames alternate between the two queue slots

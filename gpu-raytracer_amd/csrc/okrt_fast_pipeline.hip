@@ -210,25 +210,27 @@ void fastDestroy(FastScene* fs) {
     delete fs;
 }
 
-LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
-                        unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
-                        const LaunchOrder& order, std::string& err) {
-    FastScene::LaunchSlot& ls = fs.slot[order.slot % kPipelineSlots];
-    const uint32_t perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
-    if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)perFrame * frames > 0x7FFFFFFFull) {
+// Everything a launch set of `frames` frames needs in device memory, on queue slot `slot`: ray queues, hit records, radiance
+// slots, counters, spill slab, RenderData copy. Called by launchFast, and ahead of time by fastReserve so that a deferred
+// okrt_render learns about an allocator refusal when it is issued, not when its frames are finally launched.
+namespace {
+struct QueuePlan {
+    uint32_t perFrame, total, cap, lastBounce;
+    size_t items, pixels;
+    float4* radiance;
+};
+LaunchStatus ensureQueues(FastScene& fs, FastScene::LaunchSlot& ls, const SceneView& s, const TileView& t, uint32_t frames, bool frameSlots, hipStream_t stream,
+                          QueuePlan& qp, std::string& err) {
+    qp.perFrame = (((t.W + 7) >> 3) * ((t.rows + 7) >> 3)) << 6;  // camera rays of one frame incl. tile padding
+    if (frames < 1 || frames > kMaxFramesPerLaunch || (uint64_t)qp.perFrame * frames > 0x7FFFFFFFull) {
         err = "frames per launch out of range";
         return LaunchStatus::Invalid;
     }
     const FailAllocScope failScope;
-    hipError_t he = hipSuccess;
-    auto hipFailed = [&](hipError_t e, const char* what) {
-        if (e == hipSuccess) return false;
-        err = std::string(what) + ": " + hipGetErrorString(e);
-        return true;
-    };
-    const uint32_t total = perFrame * frames;
-    const uint32_t cap = (((total + kShards - 1) / kShards + 255) / 256) * 256;
-    const size_t items = (size_t)cap * kShards;
+    qp.total = qp.perFrame * frames;
+    qp.cap = (((qp.total + kShards - 1) / kShards + 255) / 256) * 256;
+    qp.items = (size_t)qp.cap * kShards;
+    const size_t items = qp.items;
     // Queue 1 (56 B per item) and the hit records (20 B) are always needed. Queue 0 only exists when something uses it:
     // the unfused camera segment (generate -> trace -> shade) or a third segment (queues ping-pong from b = 2 on); with
     // the fused camera kernel and NUM_BOUNCES = 1 — the reference's configuration — it is never allocated: 76 instead of
@@ -236,7 +238,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     static const bool envPacket0 = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused0 = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
     const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2;
-    const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 || order.frameSlots ? (size_t)t.rows * t.W * frames * 16 : 0);
+    const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 || frameSlots ? (size_t)t.rows * t.W * frames * 16 : 0);
     if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
         err = "launch set exceeds the queue memory budget";
         return LaunchStatus::OutOfMemory;
@@ -262,19 +264,19 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
             return LaunchStatus::OutOfMemory;
         ls.capacityQ0 = ls.capacity;
     }
-    const size_t pixels = (size_t)t.rows * t.W;
-    float4* radiance = nullptr;
-    if (frames > 1 || order.frameSlots) {  // (a set that shares the GPU with its neighbour adds its radiance in a later, ordered step too)
-        if (pixels * frames > ls.radianceCap) {
+    qp.pixels = (size_t)t.rows * t.W;
+    qp.radiance = nullptr;
+    if (frames > 1 || frameSlots) {  // (a set that shares the GPU with its neighbours adds its radiance in a later, ordered step too)
+        if (qp.pixels * frames > ls.radianceCap) {
             hipStreamSynchronize(stream);
             ls.radianceCap = 0;
-            if (!devAlloc(&ls.radiance, pixels * frames, err)) return LaunchStatus::OutOfMemory;
-            ls.radianceCap = pixels * frames;
+            if (!devAlloc(&ls.radiance, qp.pixels * frames, err)) return LaunchStatus::OutOfMemory;
+            ls.radianceCap = qp.pixels * frames;
         }
-        radiance = ls.radiance;
+        qp.radiance = ls.radiance;
     }
-    const uint32_t lastBounce = s.maxBounces;
-    if (lastBounce + 2 > kMaxSegments) {
+    qp.lastBounce = s.maxBounces;
+    if (qp.lastBounce + 2 > kMaxSegments) {
         err = "max_bounces too large for the fast pipeline";
         return LaunchStatus::Invalid;
     }
@@ -286,6 +288,31 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         if (!devAlloc(&ls.overflow, (size_t)fs.traceBlocks * kTraceThreads * fs.overflowCap, err)) return LaunchStatus::OutOfMemory;
         ls.overflowCap = fs.overflowCap;
     }
+    return LaunchStatus::Ok;
+}
+}  // namespace
+
+LaunchStatus fastReserve(FastScene& fs, const SceneView& s, const TileView& t, uint32_t frames, uint32_t slot, bool frameSlots, hipStream_t stream, std::string& err) {
+    QueuePlan qp;
+    return ensureQueues(fs, fs.slot[slot % kPipelineSlots], s, t, frames, frameSlots, stream, qp, err);
+}
+
+LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_data& rd, const TileView& t, float4* accum, uint32_t* result,
+                        unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
+                        const LaunchOrder& order, std::string& err) {
+    FastScene::LaunchSlot& ls = fs.slot[order.slot % kPipelineSlots];
+    QueuePlan qp;
+    const LaunchStatus qs = ensureQueues(fs, ls, s, t, frames, order.frameSlots, stream, qp, err);
+    if (qs != LaunchStatus::Ok) return qs;
+    const uint32_t perFrame = qp.perFrame, total = qp.total, cap = qp.cap, lastBounce = qp.lastBounce;
+    const size_t items = qp.items, pixels = qp.pixels;
+    float4* const radiance = qp.radiance;
+    hipError_t he = hipSuccess;
+    auto hipFailed = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return false;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return true;
+    };
     if (hipFailed(hipMemsetAsync(ls.counts, 0, (size_t)kAllCountWords * sizeof(uint32_t), stream), "hipMemsetAsync(queue counters)")) return LaunchStatus::Device;
     FastView fv{fs.nodes.p, fs.tris.p, ls.overflow, ls.overflowCap};
     const dim3 tg(fs.traceBlocks);

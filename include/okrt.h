@@ -143,8 +143,9 @@ typedef enum okrt_option {
      * RenderData apart from numAccumulationFrames = previous + 1, fast traversal, no debug mode, library-owned stream
      * and framebuffers) are deferred and up to n of them traced by one set of kernel launches — the reference's
      * main loop `for (;;) render();` (Application.cpp:106-128) gets the throughput of okrt_render_frames without a
-     * change to the host. Arguments and tables are validated inside the deferred call itself; what can only surface
-     * later (at the call that executes the frames) is a failing device allocation or launch. Every other entry point
+     * change to the host. Arguments and tables are validated inside the deferred call itself, and the queues its launch
+     * set will need are allocated as soon as a second frame waits (an allocator refusal is reported there, inside the
+     * host's loop, after smaller set sizes have been tried); what can only surface later (at the call that executes the frames) is a failing launch. Every other entry point
      * (read-backs, synchronize, uploads that change a table, options, timers, ...) executes the waiting frames first,
      * so nothing can observe the deferral; the framebuffers are bit-identical to immediate execution. 0 or 1 = launch
      * every frame inside its own okrt_render.

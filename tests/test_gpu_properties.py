@@ -495,3 +495,34 @@ def test_two_launch_sets_in_flight_are_bit_identical_to_one_at_a_time():
     assert (a[3][..., 3] == 17).all()
     c = run(4)  # the default
     assert np.array_equal(c[3], b[3], equal_nan=True) and np.array_equal(c[4], b[4])
+
+
+def test_a_deferring_render_reports_the_allocator_refusal_itself():
+    """OKRT_OPT_DEFER: the queues of the deferred launch set are allocated as soon as a second frame waits, so running out
+    of memory is reported inside the host's render loop — here the injected refusal halves the set size, the loop goes on,
+    and the picture is the one immediate execution gives — instead of at whichever unrelated call flushes later."""
+    desc = scenes.small_mesh_scene(seed=4, n_objects=5, detail=10, with_lights=True)
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.ctx.set_option(abi.OPT_DEFER, 0)
+    for _ in range(20):
+        rt.render()
+    want = rt.ctx.read_accum().copy()
+    rt.close()
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.ctx.set_option(abi.OPT_DEFER, 16)
+    rt.render()                                        # waits alone: nothing reserved yet
+    rt.ctx.set_option(abi.OPT_DEBUG_FAIL_ALLOC, 3)     # (setting an option executes the waiting frame)
+    rt.render()
+    rt.render()                                        # second waiting frame: reserves 16 frames -> refused -> 8 frames
+    rt.ctx.set_option(abi.OPT_DEBUG_FAIL_ALLOC, 0)
+    for _ in range(17):
+        rt.render()
+    got = rt.ctx.read_accum()
+    assert np.array_equal(got, want, equal_nan=True) and (got[..., 3] == 20).all()
+    rt.ctx.set_option(abi.OPT_TIMING, 8)
+    for _ in range(16):
+        rt.render()
+    rt.ctx.synchronize()
+    _, launches, frames = rt.ctx.interval_ms()
+    assert (launches, frames) == (2, 16)  # the remembered limit: sets of 8
+    rt.close()
