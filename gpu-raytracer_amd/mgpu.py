@@ -41,8 +41,12 @@ def launch_plan(gpus_arg, env, visible_gpus):
         if not 0 <= rank < world_env:
             raise ValueError(f"RANK {rank} outside WORLD_SIZE {world_env}")
         vis = visible_gpus if visible_gpus else world_env
-        return dict(mode="process_per_gpu", world=world_env, rank=rank, local_ranks=[rank], devices=[local_rank % vis],
-                    rehearsal=visible_gpus is not None and visible_gpus < world_env)
+        # a launcher that narrows every rank's view to its own GPU (HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES naming one device)
+        # leaves one visible GPU per process, and they are DIFFERENT GPUs: device 0 everywhere, not a rehearsal
+        masks = [env.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if env.get(k)]
+        own_gpu = visible_gpus == 1 and any(len(m.split(",")) == 1 for m in masks)
+        return dict(mode="process_per_gpu", world=world_env, rank=rank, local_ranks=[rank], devices=[0 if own_gpu else local_rank % vis],
+                    rehearsal=visible_gpus is not None and visible_gpus < world_env and not own_gpu)
     n = max(int(gpus_arg), 1)
     if n == 1:
         return dict(mode="single", world=1, rank=0, local_ranks=[0], devices=[0], rehearsal=False)

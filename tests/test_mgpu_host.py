@@ -33,6 +33,10 @@ def test_launch_plan_plain_and_under_a_launcher():
     assert p == dict(mode="process_per_gpu", world=4, rank=2, local_ranks=[2], devices=[2], rehearsal=False)
     p = lp(4, env, 1)
     assert p["devices"] == [0] and p["rehearsal"]
+    # a launcher that gives every rank its own GPU through a visibility mask: one visible device per process, NOT a rehearsal
+    p = lp(4, dict(env, HIP_VISIBLE_DEVICES="2"), 1)
+    assert p["devices"] == [0] and not p["rehearsal"]
+    assert lp(4, dict(env, HIP_VISIBLE_DEVICES="0,1,2,3"), 1)["rehearsal"]  # a mask of several devices but one visible: still shared
     assert lp(4, dict(WORLD_SIZE="1", RANK="0"), 8)["mode"] == "one_process"  # WORLD_SIZE=1 is no launcher at all
     with pytest.raises(ValueError):
         lp(1, dict(WORLD_SIZE="2", RANK="5"), 2)
