@@ -297,6 +297,11 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="consecutive frames traced by one set of kernel launches (okrt_render_frames); 0 = auto")
     args = ap.parse_args()
+    # stdout carries ONE JSON line and nothing else: libraries that greet on stdout (RCCL prints a version banner from its
+    # first communicator) are sent to stderr for the length of the run; the line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails with
     # "hipIpcGetMemHandle: invalid argument" (must be in the environment before the HIP runtime initialises)
@@ -313,6 +318,7 @@ def main():
     world, rank = plan["world"], plan["rank"]
     args.gpus = world
     store = mgpu.FileStore(rank, world) if plan["mode"] == "process_per_gpu" else None
+    plan = mgpu.settle_shared_devices(plan, store, os.environ)  # ranks that turn out to share a GPU: rehearsal
 
     builder, kwargs, W, H, wl_desc = WORKLOADS[args.workload]
     desc = getattr(scenes, builder)(**kwargs)
@@ -546,7 +552,7 @@ def main():
                                           shade_ms / frames, other_ms / frames)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, W, H, None)
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     group.close()
     for st in ranks:

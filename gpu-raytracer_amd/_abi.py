@@ -114,6 +114,7 @@ PRODUCT_ONLY = {
 KAT_PCG_HASH, KAT_RANDOM_FLOAT, KAT_RAY_SPHERE, KAT_RAY_TRIANGLE, KAT_RAY_AABB, KAT_REFRACT, KAT_SAMPLE_TEXTURE, KAT_SAMPLE_ENV, KAT_CLOSEST_HIT, KAT_CLOSEST_HIT_FAST = range(10)
 KAT_RANDOM_VECTOR, KAT_REFLECTANCE, KAT_REFLECT_DIRECTION, KAT_TRANSPARENCY_BOUNCE, KAT_PRIMARY_RAY = range(10, 15)
 KAT_SEGMENT_RAY = 15
+KAT_IEEE_SHORTCUTS = 16
 HEADER_SYMBOLS = ["okrt_" + n for n in list(SIGNATURES) + list(PRODUCT_ONLY)]
 
 

@@ -600,7 +600,8 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
         // allocated NOW, so that an allocator refusal is reported inside the loop, by a call that defers, and not by whichever
         // unrelated call happens to flush (smaller launch sets are tried first, like renderBatched does). A host that looks
         // at every frame never gets here and keeps single-frame queues.
-        uint32_t n = std::min(c->deferMax, c->batchLimit);
+        const uint32_t want = std::min(c->deferMax, c->batchLimit);
+        uint32_t n = want;
         std::string msg;
         for (;;) {
             const LaunchStatus ls = fastReserve(*c->fast, makeView(c), c->tile, n, 0u, n > 1, c->stream, msg);
@@ -608,7 +609,7 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
             if (ls != LaunchStatus::OutOfMemory || n == 1) return fail(c, ls == LaunchStatus::OutOfMemory ? OKRT_ERR_OOM : OKRT_ERR_DEVICE, "fast pipeline: " + msg);
             n /= 2;
         }
-        c->batchLimit = std::min(c->batchLimit, n);
+        if (n < want) c->batchLimit = n;  // (only a refusal lowers the limit: okrt_render_frames keeps its larger sets otherwise)
         c->deferReserved = true;
     }
     if (c->pending) {
@@ -1078,8 +1079,8 @@ okrt_status okrt_get_interval_ms(okrt_ctx* c, float* out_ms, uint32_t capacity, 
 }
 
 okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats) {
-    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_SEGMENT_RAY) return OKRT_ERR_INVALID_ARG;
-    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7, 1, 2, 8, 8, 62, 63}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5, 4, 1, 4, 4, 7, 8};
+    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_IEEE_SHORTCUTS) return OKRT_ERR_INVALID_ARG;
+    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7, 1, 2, 8, 8, 62, 63, 2}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5, 4, 1, 4, 4, 7, 8, 4};
     if (in_floats < needIn[op] || out_floats < needOut[op]) return fail(c, OKRT_ERR_INVALID_ARG, "kat: record too short for this probe");
     OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));

@@ -95,9 +95,39 @@ OKRT_DEV float dot(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)
 OKRT_DEV V3 cross(V3 a, V3 b) {
     return mk(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
 }
-OKRT_DEV float rsq(float x) { return 1.0f / sqrtf(x); }
+// IEEE 1/x and sqrt(x) — the same bits as the compiler's `1.f / x` and `sqrtf(x)` for EVERY float (tests/test_gpu_kats.py
+// runs all 2^32 patterns through both) — without the general-purpose sequences (10 and 16 instructions: operand scaling for
+// denormal inputs / results, v_div_fixup, class checks). In the middle of the exponent range, where every operand of a
+// traversal lives, the hardware estimate is within one ulp and needs only the last step of those sequences: one Newton
+// step in fma arithmetic for the reciprocal, the residual test against the two neighbours for the root. Anything else
+// takes the compiler's sequence.
+#ifndef OKRT_EXACT_SHORT
+#define OKRT_EXACT_SHORT 1
+#endif
+OKRT_DEV float ieeeRcp(float x) {
+#if OKRT_EXACT_SHORT
+    if (((__float_as_uint(x) >> 23) & 255u) - 27u > 200u) return 1.0f / x;  // outside 2^-100 <= |x| < 2^101 (zero, denormal, huge, inf, nan)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fma_(r, fma_(-x, r, 1.0f), r);
+#else
+    return 1.0f / x;
+#endif
+}
+OKRT_DEV float ieeeSqrt(float x) {
+#if OKRT_EXACT_SHORT
+    if (!(x >= 0x1p-100f && x < 0x1p101f)) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float resBelow = fma_(-below, s, x), resAbove = fma_(-above, s, x);
+    const float t = resBelow <= 0.f ? below : s;
+    return resAbove > 0.f ? above : t;
+#else
+    return sqrtf(x);
+#endif
+}
+OKRT_DEV float rsq(float x) { return ieeeRcp(ieeeSqrt(x)); }
 OKRT_DEV V3 normalize(V3 v) { return v * rsq(dot(v, v)); }
-OKRT_DEV float length(V3 v) { return sqrtf(dot(v, v)); }
+OKRT_DEV float length(V3 v) { return ieeeSqrt(dot(v, v)); }
 OKRT_DEV float lerp(float a, float b, float t) { return fma_(t, b - a, a); }
 OKRT_DEV V3 lerp(V3 a, V3 b, float t) { return mk(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t)); }
 OKRT_DEV V3 reflect(V3 i, V3 n) { float d = dot(i, n); return fma3(n, -(d + d), i); }
@@ -164,7 +194,7 @@ OKRT_DEV float rayAndTriangleEdges(V3 ro, V3 rd, V3 p2, V3 E1, V3 E2, float& u, 
     V3 cross1 = cross(rd, E2);
     float determinant = dot(E1, cross1);
     if (determinant < EPSILON && determinant > -EPSILON) return -1.f;
-    float inverseDet = 1.f / determinant;
+    float inverseDet = ieeeRcp(determinant);
     V3 rayMoved = ro - p2;
     u = dot(rayMoved, cross1) * inverseDet;
     if (u < -EPSILON) return -1.f;
@@ -186,7 +216,7 @@ OKRT_DEV float rayAndAABBDist(V3 ro, V3 inv, V3 bbMin, V3 bbMax) {
     bool didHit = distFar >= distNear && distFar > 0.f;
     return didHit ? distNear : kFltMax;
 }
-OKRT_DEV V3 rcp3(V3 d) { return mk(1.f / d.x, 1.f / d.y, 1.f / d.z); }
+OKRT_DEV V3 rcp3(V3 d) { return mk(ieeeRcp(d.x), ieeeRcp(d.y), ieeeRcp(d.z)); }
 
 // ---- sampling -------------------------------------------------------------------------------------
 // D3D11 fixed-function filtering is outside the reference repository; the definition used (and

@@ -108,6 +108,7 @@ struct FastView {
     const float4* tris;    // Tri48 as 3 x float4
     uint2* overflow;       // per-thread spill slab
     uint32_t overflowCap;  // entries per thread
+    uint32_t nodeBytes, triBytes;  // sizes of the two tables (< 4 GiB each): the bounds of traceKernel's buffer descriptors
 };
 
 // Shading of one path segment from its hit record (RaytracerCS.hlsl:440-513): surface fetch, lights, environment on a

@@ -136,6 +136,10 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
             return false;
         }
     }
+    if ((uint64_t)fs.numNodes * sizeof(Node4Q) > 0xFFFFFFFFull || (uint64_t)fs.numTris * sizeof(Tri48) > 0xFFFFFFFFull) {
+        err = "traversal structure: a table of 4 GiB or more (the bounce-ray kernel addresses nodes and triangles with 32-bit byte offsets)";
+        return false;
+    }
     fs.info = {builder, fs.numNodes, fs.numTris, fs.maxDepth, deviceMs,
                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()};
     // spill slab: a visit pushes at most 3 entries, so 3*depth bounds the stack
@@ -314,7 +318,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         return true;
     };
     if (hipFailed(hipMemsetAsync(ls.counts, 0, (size_t)kAllCountWords * sizeof(uint32_t), stream), "hipMemsetAsync(queue counters)")) return LaunchStatus::Device;
-    FastView fv{fs.nodes.p, fs.tris.p, ls.overflow, ls.overflowCap};
+    FastView fv{fs.nodes.p, fs.tris.p, ls.overflow, ls.overflowCap, (uint32_t)(fs.numNodes * sizeof(Node4Q)), (uint32_t)(fs.numTris * sizeof(Tri48))};
     const dim3 tg(fs.traceBlocks);
     const dim3 sg((unsigned)(items / 256));
     const bool cnt = counters != nullptr;

@@ -4,9 +4,27 @@
 //   fastKatKernel       one thread per ray, the known-answer probe
 #include "okrt_fast_internal.h"
 
+#ifndef OKRT_ASM_POP
+#define OKRT_ASM_POP 1
+#endif
+
 namespace okrt {
 namespace fastdetail {
 namespace {
+
+typedef uint32_t bufu4_t __attribute__((ext_vector_type(4)));
+constexpr int kRawBufferWord3 = 0x00020000;  // untyped 32-bit data, no swizzle: the raw-buffer descriptor word of gfx9-family parts
+__device__ __forceinline__ uint4 bufLoad16(__amdgpu_buffer_rsrc_t r, uint32_t byteOffset) {
+    const bufu4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteOffset, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// 8 bytes from LDS with one ds_read_b64, kept out of the optimiser's reach (`p` must point into __shared__ memory)
+__device__ __forceinline__ uint2 ldsRead64(const uint2* p) {
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint2*)p;
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
 
 // ---- per-ray traversal ---------------------------------------------------------------------------------------------
 // Persistent waves; every iteration a lane does ONE unit of work, a node visit or a triangle test ("if-if" scheduling;
@@ -14,13 +32,16 @@ namespace {
 // very different numbers of steps before their next leaf, waited for the slowest one). A lane's pending work sits in two
 // registers: `cur`, the node to visit next, and `leaf`, the leaf whose triangles are being tested; the wave runs ONE
 // step block per iteration, the one more lanes can join (triangles from kDualTriMin takers, or when they outnumber the
-// nodes), and all loads of the block are issued through one pointer per lane before anything is computed. Round 3
+// nodes), and all loads of the block are issued before anything is computed (buffer loads: one descriptor per table, a
+// 32-bit offset per lane). Round 3
 // measurements that shaped it (Sponza-class / 871 k-triangle scene, bounce trace ms per frame, 64-frame sets):
 //   round-2 kernel (both blocks per iteration above lane thresholds, flat-addressed pops)        0.274 / 0.152
 //   this loop                                                                                    0.252 / 0.140
 //   ... with a parked leaf while the lane traverses on (OKRT_DUAL_SPECULATE=1: +9 % node visits)  0.282 / 0.163
 //   ... both blocks in one iteration above thresholds (OKRT_DUAL_POLICY=0)                        0.269 / 0.143
 //   ... 8 waves per SIMD (64 VGPRs: 48-56 B of scratch in the loop)                               0.659 / 0.383
+//   this loop with buffer loads instead of 64-bit global addresses                               0.233 / 0.134
+//   ... triangles (and nodes below the first visits) with sc1 / nt cache policy, to keep them out of L1   0.242-0.47 / 0.18-0.41
 template <bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceKernel(
     FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q, HitBuffer hb, ShardView sv, uint32_t cameraFrames, unsigned long long* counters,
@@ -35,6 +56,12 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         if (cameraFrames) atomicAdd(&rayTotals[0], n);
         atomicAdd(&rayTotals[1], n);
     }
+    // Nodes and triangles are fetched through buffer descriptors: a 32-bit byte offset per lane instead of a 64-bit address
+    // (two fewer VALU instructions per fetch and half the address registers; bounce trace 0.242 -> 0.233 ms per frame on the
+    // Sponza-class scene, 0.137 -> 0.134 on the 871 k one), and a reference outside its table reads zeros instead of faulting.
+    // Both tables stay below 4 GiB (fastBuild refuses larger ones; a D3D11 buffer cannot hold more than 2 GiB anyway).
+    const __amdgpu_buffer_rsrc_t nodeRsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fv.nodes, 0, fv.nodeBytes, kRawBufferWord3);
+    const __amdgpu_buffer_rsrc_t triRsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fv.tris, 0, fv.triBytes, kRawBufferWord3);
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     uint32_t shard = sv.xcdAffinity ? (xcc & (kShards - 1)) : 0u, tried = 0, resNext = 0, resEnd = 0;
@@ -60,7 +87,14 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         while (sp > 0) {
             --sp;
             uint2 e;
-            if (sp < (uint32_t)kLdsStack) e = sStack[sp][tid];  // (kept apart from the spill slab: one ds_read_b64, not a flat load)
+#if OKRT_ASM_POP
+            // (left to itself the compiler merges the two sources into ONE flat load through a selected 64-bit address and
+            // fetches the reference with a second, dependent flat load after the loop; the entry is in LDS in all but the
+            // deepest corners of the tree and one ds_read_b64 brings both halves)
+            if (sp < (uint32_t)kLdsStack) e = ldsRead64(&sStack[sp][tid]);
+#else
+            if (sp < (uint32_t)kLdsStack) e = sStack[sp][tid];
+#endif
             else e = myOverflow[sp - kLdsStack];
             if (__uint_as_float(e.y) < best) return e.x;
         }
@@ -200,12 +234,17 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         if (runTri) { stTriWave++; stTriLane += __popcll(__ballot(stepTri)); }
 #endif
         uint4 d0, d1, d2, d3;
-        if (stepNode || stepTri) {
-            const uint4* p = stepNode ? fv.nodes + (size_t)cur * 4 : (const uint4*)fv.tris + (size_t)((leaf & 0x07FFFFFFu) + triJ) * 3;
-            d0 = p[0];
-            d1 = p[1];
-            d2 = p[2];
-            if (stepNode) d3 = p[3];
+        if (stepNode) {
+            const uint32_t off = cur * 64u;
+            d0 = bufLoad16(nodeRsrc, off);
+            d1 = bufLoad16(nodeRsrc, off + 16);
+            d2 = bufLoad16(nodeRsrc, off + 32);
+            d3 = bufLoad16(nodeRsrc, off + 48);
+        } else if (stepTri) {
+            const uint32_t off = ((leaf & 0x07FFFFFFu) + triJ) * 48u;
+            d0 = bufLoad16(triRsrc, off);
+            d1 = bufLoad16(triRsrc, off + 16);
+            d2 = bufLoad16(triRsrc, off + 32);
         }
         if (stepNode) {
             const uint4 n0 = d0, n1 = d1, n2 = d2, n3 = d3;

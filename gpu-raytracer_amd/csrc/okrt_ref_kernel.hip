@@ -327,6 +327,21 @@ __global__ __launch_bounds__(256) void katKernel(SceneView s, uint32_t op, uint3
             o[7] = __uint_as_float(seed);
             break;
         }
+        case OKRT_KAT_IEEE_SHORTCUTS: {  // first bit pattern, count -> patterns where ieeeRcp / ieeeSqrt differ from the compiler's 1/x / sqrtf
+            uint32_t badRcp = 0, badSqrt = 0, firstRcp = 0, firstSqrt = 0;
+            const uint32_t first = __float_as_uint(a[0]), count = __float_as_uint(a[1]);
+            for (uint32_t j = 0; j < count; ++j) {
+                const float x = __uint_as_float(first + j);
+                const float q0 = 1.0f / x, q1 = ieeeRcp(x), r0 = sqrtf(x), r1 = ieeeSqrt(x);
+                const bool sameQ = __float_as_uint(q0) == __float_as_uint(q1) || (q0 != q0 && q1 != q1);
+                const bool sameR = __float_as_uint(r0) == __float_as_uint(r1) || (r0 != r0 && r1 != r1);
+                if (!sameQ && !badRcp++) firstRcp = first + j;
+                if (!sameR && !badSqrt++) firstSqrt = first + j;
+            }
+            o[0] = __uint_as_float(badRcp); o[1] = __uint_as_float(badSqrt);
+            o[2] = __uint_as_float(firstRcp); o[3] = __uint_as_float(firstSqrt);
+            break;
+        }
         default: break;
     }
 }

@@ -55,6 +55,21 @@ def launch_plan(gpus_arg, env, visible_gpus):
                 rehearsal=visible_gpus is not None and visible_gpus < n)
 
 
+def settle_shared_devices(plan, store, env):
+    """Under a launcher no rank can tell alone whether its peers sit on the same GPU: a box whose one GPU is exposed through
+    a visibility mask looks, from inside a rank, exactly like a launcher that masks a GPU per rank. So the ranks compare notes
+    over the store: two ranks of one node with the same masks and the same device index share a GPU, and the job is a
+    REHEARSAL (host-memory exchange; RCCL cannot put two ranks on one device). Collective; returns the settled plan."""
+    if plan["mode"] != "process_per_gpu" or store is None:
+        return plan
+    import json
+    import socket
+    mine = json.dumps([socket.gethostname(), [env.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")],
+                       plan["devices"][0]]).encode()
+    seats = store.allgather(mine)
+    return dict(plan, rehearsal=len(set(seats)) < len(seats))
+
+
 def visible_gpus(fns):
     n = C.c_int(0)
     st = fns.device_count(C.byref(n))

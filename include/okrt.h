@@ -356,12 +356,16 @@ okrt_status okrt_get_fast_structure(okrt_ctx* ctx, void* nodes64, uint32_t node_
  *   PRIMARY_RAY     px(bits) py(bits) RenderData[60 floats] -> origin[3], direction[3], seed   (:177-216, 430)
  *   SEGMENT_RAY     px(bits) py(bits) k(bits) RenderData[60 floats] -> alive?, origin[3], direction[3], seed
  *                   (the ray entering path segment k of that pixel along the reference-order path, :444-514; k = 0 is
- *                   the camera ray; alive = 0 when the path ended before segment k) */
+ *                   the camera ray; alive = 0 when the path ended before segment k)
+ * and, comparing two device-side computations with each other (no CPU counterpart):
+ *   IEEE_SHORTCUTS  first(bits) count(bits)   -> n_rcp(bits), n_sqrt(bits), first_rcp(bits), first_sqrt(bits): among the
+ *                   `count` consecutive float bit patterns from `first`, how many make the short reciprocal / square root
+ *                   of okrt_device.h differ from the compiler's IEEE `1.f / x` / `sqrtf(x)`, and the first such pattern */
 typedef enum okrt_kat {
     OKRT_KAT_PCG_HASH = 0, OKRT_KAT_RANDOM_FLOAT = 1, OKRT_KAT_RAY_SPHERE = 2, OKRT_KAT_RAY_TRIANGLE = 3, OKRT_KAT_RAY_AABB = 4,
     OKRT_KAT_REFRACT = 5, OKRT_KAT_SAMPLE_TEXTURE = 6, OKRT_KAT_SAMPLE_ENV = 7, OKRT_KAT_CLOSEST_HIT = 8,
     OKRT_KAT_CLOSEST_HIT_FAST = 9, OKRT_KAT_RANDOM_VECTOR = 10, OKRT_KAT_REFLECTANCE = 11, OKRT_KAT_REFLECT_DIRECTION = 12,
-    OKRT_KAT_TRANSPARENCY_BOUNCE = 13, OKRT_KAT_PRIMARY_RAY = 14, OKRT_KAT_SEGMENT_RAY = 15
+    OKRT_KAT_TRANSPARENCY_BOUNCE = 13, OKRT_KAT_PRIMARY_RAY = 14, OKRT_KAT_SEGMENT_RAY = 15, OKRT_KAT_IEEE_SHORTCUTS = 16
 } okrt_kat;
 okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats);
 

@@ -286,3 +286,18 @@ def test_primary_ray(gpu, oracle, lib):
         assert s.value == got[i, 6:].view(np.uint32)[0]
         assert close(got[i, :3], list(o), 1e-5, 1e-5).all() and close(got[i, 3:6], list(d), 1e-5, 1e-5).all(), i
     ort.close()
+
+
+def test_short_reciprocal_and_square_root_are_the_ieee_ones_for_every_float(gpu):
+    """okrt_device.h computes 1/x and sqrt(x) in the traversal with the hardware estimate plus the last correction step of the
+    compiler's IEEE sequence (3 and 9 instructions instead of 10 and 16) wherever the exponent is mid-range. All 2^32 bit
+    patterns go through both forms on the device: not one may differ (the conventions in okrt_device.h say IEEE divide and
+    sqrt; test_ray_triangle and test_primary_ray above compare the functions that use them bit for bit with the CPU
+    checker's true divisions and square roots)."""
+    per = 1 << 14
+    first = (np.arange(0, 1 << 32, per, dtype=np.uint64)).astype(np.uint32)
+    rec = np.stack([bits(first), bits(np.full(first.shape, per, np.uint32))], axis=1)
+    out = gpu.kat(abi.KAT_IEEE_SHORTCUTS, rec, 4).view(np.uint32)
+    bad_rcp, bad_sqrt = int(out[:, 0].sum()), int(out[:, 1].sum())
+    where = out[(out[:, 0] > 0) | (out[:, 1] > 0)][:4]
+    assert bad_rcp == 0 and bad_sqrt == 0, (bad_rcp, bad_sqrt, [[hex(int(v)) for v in row] for row in where])

@@ -526,3 +526,19 @@ def test_a_deferring_render_reports_the_allocator_refusal_itself():
     _, launches, frames = rt.ctx.interval_ms()
     assert (launches, frames) == (2, 16)  # the remembered limit: sets of 8
     rt.close()
+
+
+def test_a_granted_reservation_leaves_larger_launch_sets_alone():
+    """The reservation a deferring okrt_render makes (16 frames) is not a limit: when the allocator granted it, a later
+    okrt_render_frames(64) is still ONE launch set of 64 frames (only a refusal lowers the remembered set size)."""
+    desc = scenes.small_mesh_scene(seed=4, n_objects=4, detail=6)
+    rt, sc, res = scenes.instantiate(desc, 128, 72)
+    rt.ctx.set_option(abi.OPT_DEFER, 16)
+    for _ in range(40):
+        rt.render()
+    rt.ctx.synchronize()
+    rt.ctx.set_option(abi.OPT_TIMING, 8)
+    rt.renderFrames(64)
+    _, launches, frames = rt.ctx.interval_ms()
+    assert (launches, frames) == (1, 64)
+    rt.close()

@@ -54,8 +54,16 @@ def _store_rank(rank, world, key, root, out):
     blob = st.get("blob")
     st.barrier()
     total = m.allreduce_json(st, {"n": rank + 1}, lambda ds: sum(d["n"] for d in ds))
+    # who shares a GPU is settled between the ranks: the same one-device mask everywhere (a 1-GPU box) is a rehearsal even
+    # though each rank alone would read it as "my own GPU"; a different mask per rank is not; nor are distinct devices
+    env = dict(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    box_mask = m.settle_shared_devices(m.launch_plan(1, dict(env, HIP_VISIBLE_DEVICES="3"), 1), st, dict(env, HIP_VISIBLE_DEVICES="3"))
+    own_mask = m.settle_shared_devices(m.launch_plan(1, dict(env, HIP_VISIBLE_DEVICES=str(rank)), 1), st, dict(env, HIP_VISIBLE_DEVICES=str(rank)))
+    no_mask = m.settle_shared_devices(m.launch_plan(1, env, 8), st, env)
+    crowded = m.settle_shared_devices(m.launch_plan(1, env, 2), st, env)  # 3 ranks, 2 GPUs: ranks 0 and 2 on device 0
     st.close()
-    out.put((rank, [len(g) for g in got], [g[:1] for g in got], len(blob), total))
+    out.put((rank, [len(g) for g in got], [g[:1] for g in got], len(blob), total,
+             (box_mask["rehearsal"], own_mask["rehearsal"], no_mask["rehearsal"], crowded["rehearsal"])))
 
 
 def test_file_store_allgather_barrier_close(tmp_path):
@@ -69,8 +77,9 @@ def test_file_store_allgather_barrier_close(tmp_path):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, lens, firsts, blob, total in res:
+    for rank, lens, firsts, blob, total, shared in res:
         assert lens == [1, 2, 3] and firsts == [b"\x00", b"\x01", b"\x02"] and blob == 128 and total == 6
+        assert shared == (True, False, False, True)
     assert not [d for d in os.listdir(tmp_path) if d.startswith("okrt_rdzv_")]  # rank 0 removed the directory
 
 
