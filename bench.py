@@ -34,6 +34,19 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:36)
+# 128-byte L1 -> L2 read requests per second a pure random gather of 64-byte records sustains at the traversal kernel's occupancy
+# (tools/calib/l1_gather_rate.hip -> profiles/r03_l1_gather_rate.txt): from a table that sits in L2 (2-4 MiB: 13.9 TB/s of records), and
+# from one that sits in the Infinity Cache (64 MiB: 3.76 TB/s at 6 % L2 hits -> 56 G/s for the requests that miss L2). A kernel whose
+# requests hit L2 with probability h cannot gather faster than 1 / (h / hit_rate + (1 - h) / miss_rate).
+GATHER_L2_HIT_REQUESTS_PER_S = 215e9
+GATHER_L2_MISS_REQUESTS_PER_S = 56e9
+
+
+def gather_ceiling(l2_hit_fraction):
+    h = min(max(l2_hit_fraction, 0.0), 1.0)
+    return 1.0 / (h / GATHER_L2_HIT_REQUESTS_PER_S + (1.0 - h) / GATHER_L2_MISS_REQUESTS_PER_S)
+
+
 L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth of the 8 XCDs (same guide, "L2 (per XCD)")
 STRIPE_ROWS = 8
 GATHER_EVERY = 64
@@ -205,7 +218,10 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                         # the only pattern FETCH_SIZE under-counts (x2, profiles/r03_pmc_calibration.txt); tools/pmc_traffic.py adds it back
                         "stream_read_bytes_per_launch": int(stream_frame / per_gpu * frames_per_launch),
                         "algorithmic_frac": round(alg / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "l2_request_bytes_per_launch": int(l2), "l2_frac": round(l2 / (launch_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)})
+                        # bytes the kernel's per-lane gathers ask of the vector L1s (64 B per node visit, 48 B per triangle test, ...): an UPPER
+                        # bound of what reaches L2 — the L1s' 128-byte lines serve about two thirds of a traversal's records.
+                        # l2_read_requests / l2_frac / gather_ceiling_frac below are MEASURED (TCP_TCC_READ_REQ, attached from the PMC file)
+                        "l1_gather_bytes_per_launch": int(l2), "l2_read_requests_per_launch": None, "l2_frac": None, "gather_ceiling_frac": None})
 
     if args.traversal == "fast" and len(interval_ms) >= 2:
         # camera-segment kernel: generates, traces (wave-uniform node / triangle loads: once per WAVE), shades, appends queue 1
@@ -243,6 +259,12 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                 k["traffic_frac"] = round(m["hbm_bytes_per_launch"] / (k["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 k["l2_hit_pct"] = m.get("l2_hit_pct")
                 k["valu_lane_util"] = m.get("valu_lane_util")
+                if m.get("l2_read_requests_per_launch"):
+                    req = m["l2_read_requests_per_launch"]
+                    k["l2_read_requests_per_launch"] = int(req)
+                    k["l2_frac"] = round(req * 128 / (k["launch_ms"] * 1e-3) / 1e9 / L2_PEAK_GBS, 4)
+                    if m.get("l2_hit_pct") is not None:  # against what a pure gather with the same L2 hit rate reaches
+                        k["gather_ceiling_frac"] = round(req / (k["launch_ms"] * 1e-3) / gather_ceiling(m["l2_hit_pct"] / 100.0), 4)
         traffic, lane_util, l2_hit = head.get("traffic"), head.get("valu_lane_util"), head.get("l2_hit_pct")
     measured = traffic is not None
     achieved = (traffic if measured else head["algorithmic_bytes_per_launch"]) / (head["launch_ms"] * 1e-3) / 1e9
@@ -257,7 +279,7 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                         "FETCH_SIZE + half of the coalesced 16-B-per-lane stream reads (the one pattern it counts at half) + WRITE_SIZE" if measured else None,
         "traffic_source": pmc[0] if pmc else why,
         "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "algorithmic_frac": head["algorithmic_frac"],
-        "l2_frac": head["l2_frac"], "l2_hit_pct": l2_hit, "valu_lane_util": lane_util,
+        "l2_frac": head["l2_frac"], "gather_ceiling_frac": head["gather_ceiling_frac"], "l2_hit_pct": l2_hit, "valu_lane_util": lane_util,
         "kernels": kernels,
         "node4q_visits_per_bounce_ray": round(b_nodes / max(bounce_rays, 1), 2), "tri48_tests_per_bounce_ray": round(b_tris / max(bounce_rays, 1), 2),
         "node4q_steps_per_camera_tile": round(cam_nodes / 64 / max(pixels / 64, 1), 2), "tri48_tests_per_camera_tile": round(cam_tris / 64 / max(pixels / 64, 1), 2),
@@ -267,8 +289,8 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         # for these rays over the traversal time. Far above 1: it measures the work the derived structure avoids, not a bandwidth.
         "reference_work_ratio": round(ref_trav_bytes / per_gpu / max(trace_ms_frame * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 2),
         "reference_algorithmic_bytes_per_ray": round(ref_trav_bytes / max(ref_c["segments"], 1), 1),
-        "note": "frac <= 1 by construction. The traversal kernels are VALU-issue / latency bound (dependent gathers served by L2 and the Infinity Cache: the "
-                "structure is cache-resident), so their fabric fraction is low; the later-segment shading kernels move the most bytes per second "
+        "note": "frac <= 1 by construction. The traversal kernels are VALU-issue / latency bound (dependent gathers served by L1, L2 and the Infinity Cache: "
+                "the structure is cache-resident; gather_ceiling_frac = their measured L1 -> L2 read requests against the rate a pure gather with the same L2 hit rate reaches: close to 1 on the 871 k-triangle scene), so their fabric fraction is low; the later-segment shading kernels move the most bytes per second "
                 "(kernels[].traffic_frac), a fabric / Infinity-Cache rate on this working set, not proven HBM.",
     }
 

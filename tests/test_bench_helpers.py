@@ -62,11 +62,14 @@ def test_roofline_report_is_a_fraction_and_names_its_basis(monkeypatch):
     assert rep["kernel"].startswith("traceKernel") and rep["frames_per_launch"] == 64 and rep["traffic"] is None and rep["traffic_stale"]
     assert 0 < rep["frac"] <= 1 and "algorithmic" in rep["frac_basis"]
     for k in rep["kernels"]:
-        assert 0 < k["algorithmic_frac"] <= 1 and 0 < k["l2_frac"] <= 1, k
+        assert 0 < k["algorithmic_frac"] <= 1 and k["l2_frac"] is None and k["l1_gather_bytes_per_launch"] > 0, k  # L2 figures are measured or absent
     assert rep["reference_work_ratio"] > 1  # the reference's traversal order would touch far more bytes than HBM could deliver
     # with a matching measurement the fraction is the measured one
-    pmc = {"kernels": {"traceKernel": {"hbm_bytes_per_launch": 17.1e9, "l2_hit_pct": 84.5, "valu_lane_util": 0.565}}}
+    pmc = {"kernels": {"traceKernel": {"hbm_bytes_per_launch": 17.1e9, "l2_hit_pct": 84.5, "valu_lane_util": 0.565, "l2_read_requests_per_launch": 893e6}}}
     monkeypatch.setattr(bench, "load_pmc", lambda w, f: (("r99_pmc_sponza_f64.json", pmc), None))
     rep = bench.roofline_report(args, 1, False, [12.7, 0.01, 17.5, 6.1], 1, 64, build, ref, fast, cam, 117.9e9, 1e9, 0.47, 0.095, 0.0)
     assert rep["traffic"] == int(17.1e9) and not rep["traffic_stale"] and "measured" in rep["frac_basis"]
     assert abs(rep["frac"] - 17.1e9 / 17.5e-3 / 8e12) < 1e-3 and rep["valu_lane_util"] == 0.565
+    # measured L1 -> L2 read requests (128-byte lines): as a share of the L2 peak and of the rate a pure gather sustains
+    assert abs(rep["l2_frac"] - 893e6 * 128 / 17.5e-3 / 34.5e12) < 1e-3 and abs(rep["gather_ceiling_frac"] - 893e6 / 17.5e-3 / bench.gather_ceiling(0.845)) < 1e-3
+    assert bench.gather_ceiling(1.0) == bench.GATHER_L2_HIT_REQUESTS_PER_S and abs(bench.gather_ceiling(0.0) - bench.GATHER_L2_MISS_REQUESTS_PER_S) < 1

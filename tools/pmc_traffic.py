@@ -3,7 +3,7 @@
 
   python3 tools/pmc_traffic.py --workload sponza --frames 64 --out gpurun_out/pmc    (on the GPU box, via gpurun)
 
-Four separate passes (counters never share a run with --stats; FETCH_SIZE and WRITE_SIZE do not fit one pass:
+Five separate passes (counters never share a run with --stats; FETCH_SIZE and WRITE_SIZE do not fit one pass:
 MI355X_MICROARCH.md "rocprofv3 PMC slots"):
   1. --kernel-trace --stats                     per-kernel launch durations (must agree with bench.py's HIP-event times)
   2. --pmc FETCH_SIZE                           L2 -> fabric read requests x 64 B (KiB). Calibrated against known bytes per access pattern
@@ -12,6 +12,10 @@ MI355X_MICROARCH.md "rocprofv3 PMC slots"):
                                                 16-B-per-lane streams (128-byte requests tallied at 64) -> half of the kernel's stream reads is added back
   3. --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum  fabric write bytes (KiB, exact), L2 hit rate
   4. --pmc SQ_* (8 slots)                       VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), wait shares
+  5. --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum   read requests the vector L1s send to L2 (128-byte lines: tools/calib/l1_gather_rate.hip
+                                                counts exactly one per random 64-byte record and 1.25-1.3 per 48-byte record) and the per-lane-instruction
+                                                accesses the L1s serve: how much of a traversal's gathering L1 absorbs, and how far the kernel is from the
+                                                request rate a pure gather reaches (profiles/r03_l1_gather_rate.txt)
 Every bench run uses --steps F --warmup F --frames-per-launch F, so every launch of the non-counting kernel variants
 traces exactly F frames and "per launch" is well defined.
 
@@ -37,6 +41,7 @@ PASSES = [
     ("write", ["--pmc", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "--kernel-trace"]),
     ("sq", ["--pmc", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
             "SQ_WAIT_INST_ANY", "--kernel-trace"]),
+    ("l1", ["--pmc", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "--kernel-trace"]),
 ]
 FAMILIES = ("tracePacketKernel", "traceKernel", "shadeKernel", "accumulateKernel", "generateKernel", "renderReferenceOrder")
 
@@ -57,7 +62,7 @@ def main():
     ap.add_argument("--workload", default="sponza")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--out", default="gpurun_out/pmc")
-    ap.add_argument("--passes", default="stats,fetch,write,sq")
+    ap.add_argument("--passes", default="stats,fetch,write,sq,l1")
     args = ap.parse_args()
     import bench
     args.out = os.path.abspath(args.out)  # rocprofv3 runs from /tmp
@@ -87,7 +92,7 @@ def main():
             if fam and not counting:
                 dur[fam].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
-    for name in ("fetch", "write", "sq"):
+    for name in ("fetch", "write", "sq", "l1"):
         for f in glob.glob(os.path.join(args.out, f"{tag}_{name}", "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 fam, counting = family(r["Kernel_Name"])
@@ -119,6 +124,11 @@ def main():
                 k["wait_any_share"] = round(avg.get("SQ_WAIT_ANY", 0.0) / wc, 4)
                 k["wait_inst_share"] = round(avg.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
                 k["valu_inst_per_wave_cycle"] = round(avg.get("SQ_INSTS_VALU", 0.0) / wc, 4)
+        if avg.get("TCP_TCC_READ_REQ_sum"):
+            k["l2_read_requests_per_launch"] = avg["TCP_TCC_READ_REQ_sum"] * per_set  # 128-byte lines
+            k["l1_accesses_per_launch"] = avg.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) * per_set
+            if k["launch_ms"]:
+                k["l2_read_requests_per_s"] = round(k["l2_read_requests_per_launch"] / (k["launch_ms"] * 1e-3), 0)
         kernels[fam] = k
     if "shadeKernel" in kernels and "accumulateKernel" in kernels:  # bench.py times them as one interval
         a, b = kernels["shadeKernel"], kernels["accumulateKernel"]
@@ -138,12 +148,12 @@ def main():
     path = os.path.join(args.out, f"pmc_{tag}.json")
     json.dump(out, open(path, "w"), indent=1)
     lines = [f"# {out['command']}", f"# source_sha {out['source_sha']}  frames per launch {args.frames}",
-             f"{'kernel':24s} {'launches':>8s} {'launch_ms':>10s} {'FETCH MiB':>10s} {'+stream/2':>10s} {'WRITE MiB':>10s} {'fabric GB/s':>11s} {'frac':>6s} {'L2hit%':>7s} {'lanes':>6s}"]
+             f"{'kernel':24s} {'launches':>8s} {'launch_ms':>10s} {'FETCH MiB':>10s} {'+stream/2':>10s} {'WRITE MiB':>10s} {'fabric GB/s':>11s} {'frac':>6s} {'L2hit%':>7s} {'lanes':>6s} {'L2 rd req G/s':>13s}"]
     for fam, k in kernels.items():
         ms = k["launch_ms"] or 0.0
         gbs = k["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 if ms else 0.0
         lines.append(f"{fam:24s} {k['launches_seen']:8d} {ms:10.3f} {k['fetch_bytes_raw'] / 2**20:10.1f} {k['stream_add_back_bytes'] / 2**20:10.1f} {k['write_bytes'] / 2**20:10.1f} {gbs:11.1f} "
-                     f"{gbs / 8000.0:6.3f} {k['l2_hit_pct'] if k['l2_hit_pct'] is not None else 0:7.1f} {k.get('valu_lane_util', 0) or 0:6.3f}")
+                     f"{gbs / 8000.0:6.3f} {k['l2_hit_pct'] if k['l2_hit_pct'] is not None else 0:7.1f} {k.get('valu_lane_util', 0) or 0:6.3f} {(k.get('l2_read_requests_per_s') or 0) / 1e9:13.1f}")
     for f in glob.glob(os.path.join(args.out, f"{tag}_stats", "*", "*_kernel_stats.csv")):
         lines.append("")
         lines.append("# rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
