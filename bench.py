@@ -266,7 +266,9 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                     # 2 % shorter than the profiled one would otherwise print a fraction above 1)
                     per_s = req / ((m.get("launch_ms") or k["launch_ms"]) * 1e-3)
                     k["l2_frac"] = round(per_s * 128 / 1e9 / L2_PEAK_GBS, 4)
-                    if m.get("l2_hit_pct") is not None:  # against what a pure gather with the same L2 hit rate reaches
+                    # against what a pure gather with the same L2 hit rate reaches — for the kernels whose requests ARE gathers (the shading
+                    # kernels also stream their queues, whole 128-byte lines at a higher rate than any gather: the ceiling does not apply)
+                    if m.get("l2_hit_pct") is not None and short in ("traceKernel", "tracePacketKernel"):
                         k["gather_ceiling_frac"] = round(per_s / gather_ceiling(m["l2_hit_pct"] / 100.0), 4)
         traffic, lane_util, l2_hit = head.get("traffic"), head.get("valu_lane_util"), head.get("l2_hit_pct")
     measured = traffic is not None
