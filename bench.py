@@ -300,6 +300,22 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
     }
 
 
+def device_memory_in_use_gb(devices):
+    """Largest bytes in use over the job's devices right now (hipMemGetInfo: total - free; everything on the device counts,
+    other processes included), or None when the runtime cannot say."""
+    try:
+        hip = C.CDLL("libamdhip64.so.7")  # the soname libokrt.so is linked against: the runtime instance already loaded
+        worst = 0
+        for d in sorted(set(devices)):
+            free, total = C.c_size_t(0), C.c_size_t(0)
+            if hip.hipSetDevice(C.c_int(d)) != 0 or hip.hipMemGetInfo(C.byref(free), C.byref(total)) != 0:
+                return None
+            worst = max(worst, total.value - free.value)
+        return round(worst / 1e9, 2)
+    except OSError:
+        return None
+
+
 class RankState:
     """One rank this process drives: its RayTracer (host layer) on its device, with the rank's tile."""
 
@@ -316,6 +332,7 @@ def main():
     ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-call", action="store_true", help="skip the one-okrt_render-per-frame and 1024-spp timings (profiling runs: every launch set then has frames_per_launch frames)")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the four untimed-for-the-headline repeats of the K-step region (profiling runs)")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
     ap.add_argument("--max-bounces", type=int, default=1, help="NUM_BOUNCES (RaytracerCS.hlsl:6; HEAD = 1, used for every graded number)")
     ap.add_argument("--split", default="tiles", choices=["tiles", "samples"],
@@ -387,7 +404,7 @@ def main():
         for st in ranks:
             st.ctx.synchronize()
         if store:
-            store.barrier()
+            store.tight_barrier()  # the ranks leave it within microseconds of each other: it brackets the timed region
 
     # ---- roofline numerator: the reference-order counters of one frame of this workload -------
     def counted(st, traversal, max_bounces):
@@ -423,15 +440,26 @@ def main():
     fpl = max(1, min(fpl, 64, gather_every))
     enqueue_s = [0.0, 0]  # host time spent inside renderFrames calls (they must only ENQUEUE: that is what lets one thread feed N GPUs)
 
+    # one process, several GPUs: every rank's launch set is enqueued from its own thread (the call is one ctypes call into the C++
+    # host layer, which releases the interpreter lock), so rank N-1's GPU starts with rank 0's instead of N-1 enqueue times later
+    enqueue_pool = None
+    if len(ranks) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        enqueue_pool = ThreadPoolExecutor(max_workers=len(ranks))
+
+    def enqueue(st, m):
+        t_enq = time.perf_counter()
+        st.rt.renderFrames(m)
+        return time.perf_counter() - t_enq
+
     def run_frames(n, gather):
         done = 0
         while done < n:
             m = min(fpl, n - done, gather_every - done % gather_every)
-            for st in ranks:  # asynchronous launches: the GPUs of a one-process job run concurrently
-                t_enq = time.perf_counter()
-                st.rt.renderFrames(m)
-                enqueue_s[0] += time.perf_counter() - t_enq
-                enqueue_s[1] += 1
+            # asynchronous launches: the GPUs of a one-process job run concurrently
+            spent = list(enqueue_pool.map(lambda st: enqueue(st, m), ranks)) if enqueue_pool else [enqueue(ranks[0], m)]
+            enqueue_s[0] += sum(spent)
+            enqueue_s[1] += len(spent)
             done += m
             if gather and done % gather_every == 0 and done != n:
                 exchange()
@@ -440,6 +468,13 @@ def main():
     # also run one full-size launch set untimed unless the warm-up already did: its queues (GBs) are allocated on first use
     extra_warm = fpl if (args.warmup == 0 or args.warmup % fpl) else 0
     run_frames(extra_warm, False)
+    # ... and the launch-set shapes of the timed region itself, twice: a K-step region that is not a multiple of the set size ends
+    # in a smaller set, small tiles issue their sets as sub-sets that take turns on four queue slots (csrc/okrt_launch_plan.h), and
+    # every slot allocates its queues on first use — 2.6 ms per rank inside a 1.7 ms region when this was missing (r04 N = 8 rehearsal)
+    k_here = args.steps // world if (world > 1 and args.split == "samples") else args.steps
+    shape_warm = k_here if k_here <= fpl else fpl + k_here % fpl
+    for _ in range(2):
+        run_frames(shape_warm, False)
     if world > 1 and not samples_split:
         exchange()  # untimed: communicator warm-up (RCCL connects its channels on first use), staging buffers allocated
     steps_here = args.steps
@@ -452,7 +487,7 @@ def main():
     sync()
     for st in ranks:
         st.ctx.reset_counters()
-    ctx.set_option(abi.OPT_TIMING, min(args.steps, 4096))  # HIP events around every kernel of every launch set, on the stream they run on
+    ctx.set_option(abi.OPT_TIMING, min(5 * args.steps, 4096))  # HIP events around every kernel of every launch set, on the stream they run on (ring: all five regions)
     enqueue_s[0], enqueue_s[1] = 0.0, 0
     sync()
     t0 = time.perf_counter()
@@ -462,18 +497,33 @@ def main():
     exchange(final=True)
     sync()
     elapsed = time.perf_counter() - t0
+    mem_gb = device_memory_in_use_gb(plan["devices"])  # queues of the timed launch sets are allocated now
     enqueue_ms_per_set = enqueue_s[0] * 1e3 / max(enqueue_s[1], 1)
     trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
     interval_ms, interval_launches, interval_frames = ctx.interval_ms()  # per kernel, launch sets of the size of the last one
     build = ctx.build_info()
-    ctx.set_option(abi.OPT_TIMING, 0)
     rays_local = sum(st.ctx.counters()["segments"] for st in ranks)
+    # The graded region above is exactly K steps, once. The same region four more times says how far one sample can be trusted
+    # (config.ms_per_step_repeats; the headline stays the first) and gives the per-kernel averages below five regions to stand on.
+    repeat_ms = [elapsed * 1e3 / args.steps]
+    repeats_done = 0
+    if not samples_split and not args.no_repeats:
+        for _ in range(4):
+            sync()
+            t1 = time.perf_counter()
+            run_frames(steps_here, True)
+            exchange(final=True)
+            sync()
+            repeat_ms.append((time.perf_counter() - t1) * 1e3 / args.steps)
+            repeats_done += 1
+        interval_ms, interval_launches, interval_frames = ctx.interval_ms()  # all five regions' launch sets (same shapes)
+    ctx.set_option(abi.OPT_TIMING, 0)
     if args.traversal == "reference":  # the reference-order kernel only counts with OKRT_OPT_COUNTERS (slow): segments of the counted frame x frames
         rays_local = ref_counters["segments"] * steps_here
     gpu_event_ms = ctx.timer_elapsed_ms()
 
     # the combined frame on rank 0: every pixel must have received every frame
-    frames_done = args.steps if samples_split else args.warmup + extra_warm + args.steps
+    frames_done = args.steps if samples_split else args.warmup + extra_warm + 2 * shape_warm + args.steps * (1 + repeats_done)
     if world > 1:
         full = group.read_full()
         if full is not None:
@@ -528,6 +578,7 @@ def main():
         return mgpu.allreduce_json(store, d, lambda ds: {k: sum(x[k] for x in ds) for k in ds[0]})
     rays_total = job_sum(rays_local)
     elapsed_max = job_max(elapsed)
+    repeat_ms = [job_max(v) for v in repeat_ms]
     if store:
         ref_counters, fast_counters, camera_counters = job_sum_dict(ref_counters), job_sum_dict(fast_counters), job_sum_dict(camera_counters)
         trace_ms, shade_ms, other_ms = job_max(trace_ms), job_max(shade_ms), job_max(other_ms)
@@ -557,6 +608,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_desc, "traversal": args.traversal, "max_bounces": args.max_bounces, "rays_per_frame": rays_total // args.steps, "frames_per_launch": fpl_used,
                        "gpu_event_ms_per_step": round(gpu_event_ms / max(steps_here, 1), 4),
+                       # the graded K-step region (first value = ms_per_step) and the same region repeated four more times
+                       "ms_per_step_repeats": [round(v, 4) for v in repeat_ms],
+                       "ms_per_step_repeats_spread": round((max(repeat_ms) - min(repeat_ms)) / min(repeat_ms), 4),
                        "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
                        "ms_per_step_one_call_per_frame_defer_off": round(single_sync_ms, 4) if single_sync_ms else None,
                        "ms_per_step_1024spp": round(spp1024_ms, 4) if spp1024_ms else None,
@@ -569,7 +623,8 @@ def main():
                        "gather": gather_desc, "gather_transport": group.transport if world > 1 else None,
                        "gather_ms": round(exchange_ms, 3) if exchange_ms is not None else None,
                        "gather_bytes_per_peer": tile["bytes"] if world > 1 else None,
-                       "host_enqueue_ms_per_launch_set": round(enqueue_ms_per_set, 3)},
+                       "host_enqueue_ms_per_launch_set": round(enqueue_ms_per_set, 3),
+                       "device_memory_in_use_gb": mem_gb},
         }
         if plan["rehearsal"]:
             out["config"]["note"] = (f"REHEARSAL: {world} ranks on fewer GPUs (devices {plan['devices']}); the ranks share GPU time, so this line says "
@@ -581,6 +636,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc, W, H, None)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
 
+    if enqueue_pool:
+        enqueue_pool.shutdown()
     group.close()
     for st in ranks:
         st.rt.close()

@@ -12,6 +12,7 @@
 
 #include "okrt_fast.h"
 #include "okrt_kernels.h"
+#include "okrt_launch_plan.h"
 
 using namespace okrt;
 
@@ -72,6 +73,11 @@ struct okrt_ctx {
     hipStream_t side[kPipelineSlots] = {};  // side[0] is unused (slot 0 runs on `stream`)
     hipEvent_t accumDone[kPipelineSlots] = {}, evJoinA = nullptr, evJoinB = nullptr;
     uint32_t pipeNext = 0, pipeLast = 0;
+    // A launch set on a SMALL tile (one rank's share of an N-way split) is issued as sub-sets that ride the pipeline slots:
+    // its fixed cost — the last dependent chains of every kernel on an emptied GPU — is a fifth of its time there, and the
+    // next sub-set's bulk fills the GPU meanwhile. Above splitRays rays per set the contention costs more than it returns.
+    uint64_t splitRays = kPipelineSplitRays;
+    uint32_t splitParts = 2;
     // okrt_peek_result_rgba8: two device-side copies of the resolved picture, refreshed alternately at the end of every
     // launch set once a host has asked for one; the peek copies the newest finished one out on its own stream
     bool peekOn = false;
@@ -87,7 +93,7 @@ struct okrt_ctx {
     std::string err;
 };
 
-static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames);  // below
+static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames, bool subSet = false);  // below
 
 namespace {
 
@@ -99,18 +105,27 @@ okrt_status fail(okrt_ctx* c, okrt_status s, const std::string& msg) {
 // Executes the deferred frames. Errors of the launch (queue memory) surface at the call that flushes.
 // `frames` consecutive frames of the accumulation loop, as few launch sets as memory allows: a launch set that cannot
 // get its queues (56+ bytes per ray and frame) is retried at half the size, and the limit is remembered.
+LaunchPlanParams planParams(const okrt_ctx* c, bool batchable) {
+    return LaunchPlanParams{c->tile.rows, c->W, c->batchLimit, c->pipelineMaxFrames, c->pipelineDepth, c->splitParts, c->splitRays,
+                            c->pipelineOn && !c->externalStream && !c->externalFramebuffers && c->traversal == OKRT_TRAVERSAL_FAST, batchable};
+}
+
 okrt_status renderBatched(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames, bool batchable) {
     okrt_render_data cur = *rd;
+    LaunchCursor lc;
     while (frames) {
-        const uint32_t n = batchable ? std::min<uint32_t>(frames, c->batchLimit) : 1u;
-        const okrt_status s = renderImpl(c, &cur, n);
+        const LaunchStep step = nextLaunch(planParams(c, batchable), lc, frames);  // okrt_launch_plan.h
+        const uint32_t n = step.frames;
+        const okrt_status s = renderImpl(c, &cur, n, step.subSet);
         if (s == OKRT_ERR_OOM && n > 1) {
-            c->batchLimit = n / 2;
+            c->batchLimit = step.subSet ? n : n / 2;  // (a refused sub-set: whole sets of its size are issued in halves again)
+            lc = LaunchCursor{};
             continue;
         }
         if (s != OKRT_OK) return s;
         if (cur.accumulationEnabled == 1) cur.numAccumulationFrames += n;  // the host's pre-increment per frame (RayTracer.cpp:489)
         frames -= n;
+        launched(lc, n);
     }
     return OKRT_OK;
 }
@@ -341,6 +356,8 @@ okrt_status okrt_create(int device, okrt_ctx** out) {
     hipEventCreate(&c->evBegin);
     hipEventCreate(&c->evEnd);
     if (const char* d = getenv("OKRT_PIPELINE_DEPTH")) c->pipelineDepth = std::min<uint32_t>(std::max(atoi(d), 2), kPipelineSlots);
+    if (const char* d = getenv("OKRT_PIPELINE_SPLIT_RAYS")) c->splitRays = strtoull(d, nullptr, 10);
+    if (const char* d = getenv("OKRT_PIPELINE_SPLIT_PARTS")) c->splitParts = std::min<uint32_t>(std::max(atoi(d), 1), kPipelineSlots);
     for (uint32_t k = 1; k < kPipelineSlots; ++k) {
         c->sideNeedsSync[k] = true;
         if (hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) != hipSuccess) c->side[k] = nullptr, c->pipelineOn = false;
@@ -600,11 +617,22 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
         // allocated NOW, so that an allocator refusal is reported inside the loop, by a call that defers, and not by whichever
         // unrelated call happens to flush (smaller launch sets are tried first, like renderBatched does). A host that looks
         // at every frame never gets here and keeps single-frame queues.
+        // (reserved the way the flush will launch it, renderBatched / renderImpl: a set that rides the pipeline slots — small, or
+        // issued in sub-sets — keeps its radiance in frame slots and lands on whichever slot's turn it is, so every slot in use
+        // gets its queues; a big set runs on slot 0)
         const uint32_t want = std::min(c->deferMax, c->batchLimit);
         uint32_t n = want;
         std::string msg;
         for (;;) {
-            const LaunchStatus ls = fastReserve(*c->fast, makeView(c), c->tile, n, 0u, n > 1, c->stream, msg);
+            LaunchPlanParams pp = planParams(c, true);
+            pp.batchLimit = n;
+            LaunchCursor lc;
+            const LaunchStep first = nextLaunch(pp, lc, n);
+            const uint32_t sub = first.frames;
+            const bool rides = ridesSlots(pp, first);
+            LaunchStatus ls = LaunchStatus::Ok;
+            for (uint32_t k = 0; k < (rides ? c->pipelineDepth : 1u) && ls == LaunchStatus::Ok; ++k)
+                ls = fastReserve(*c->fast, makeView(c), c->tile, sub, k, rides || sub > 1, k ? c->side[k] : c->stream, msg);
             if (ls == LaunchStatus::Ok) break;
             if (ls != LaunchStatus::OutOfMemory || n == 1) return fail(c, ls == LaunchStatus::OutOfMemory ? OKRT_ERR_OOM : OKRT_ERR_DEVICE, "fast pipeline: " + msg);
             n /= 2;
@@ -709,7 +737,7 @@ okrt_status okrt_get_fast_structure(okrt_ctx* c, void* nodes64, uint32_t node_ca
     return OKRT_OK;
 }
 
-static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames) {
+static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames, bool subSet) {
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
     okrt_status as = checkRenderArgs(c, rd);
     if (as != OKRT_OK) return as;
@@ -746,7 +774,7 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
     // accumulation kernel waits for the previous set's. Larger sets (OKRT_OPT_PIPELINE) stay on one slot: their fixed
     // cost is already amortised and two big persistent grids sharing the GPU cost more than the overlap returns.
     const bool pipelined = c->pipelineOn && !referenceOrder && !c->externalStream && !c->externalFramebuffers && rd->accumulationEnabled == 1 &&
-                           frames <= c->pipelineMaxFrames;
+                           (frames <= c->pipelineMaxFrames || subSet);
     // The debug heat maps count the REFERENCE traversal's box/triangle checks (RaytracerCS.hlsl:516-520),
     // so those frames always run the reference-order kernel.
     if (referenceOrder) {
@@ -765,13 +793,20 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
             order.frameSlots = true;
             order.after = c->accumChain ? c->accumDone[c->pipeLast] : nullptr;
             order.done = c->accumDone[order.slot];
-            if (order.slot != 0u) {
-                launchStream = c->side[order.slot];
-                if (c->sideNeedsSync[order.slot]) {  // uploads, resets, ... made on the main stream since this side stream last ran
-                    OKRT_HIP(c, hipEventRecord(c->evJoinA, c->stream));
-                    OKRT_HIP(c, hipStreamWaitEvent(launchStream, c->evJoinA, 0));
-                    c->sideNeedsSync[order.slot] = false;
-                }
+            if (order.slot != 0u) launchStream = c->side[order.slot];
+            // Uploads, resets, ... made on the main stream since the side streams last ran: ordered before whatever the side
+            // streams do next, for ALL of them at once and BEFORE this set is enqueued. (Round 3 recorded the event when a
+            // side stream was next used: by then a set on slot 0 = the main stream may already sit in front of it, and the
+            // side stream's set waited for that whole set instead of running beside it.)
+            bool anyNeedsSync = false;
+            for (uint32_t k = 1; k < kPipelineSlots; ++k) anyNeedsSync |= c->sideNeedsSync[k] && c->side[k];
+            if (anyNeedsSync) {
+                OKRT_HIP(c, hipEventRecord(c->evJoinA, c->stream));
+                for (uint32_t k = 1; k < kPipelineSlots; ++k)
+                    if (c->sideNeedsSync[k] && c->side[k]) {
+                        OKRT_HIP(c, hipStreamWaitEvent(c->side[k], c->evJoinA, 0));
+                        c->sideNeedsSync[k] = false;
+                    }
             }
         } else {  // accumulates from inside its kernels, on the main stream: after everything B still has in flight
             okrt_status js = joinStreams(c);
@@ -810,6 +845,9 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
             if (c->peekRecorded[k]) OKRT_HIP(c, hipStreamWaitEvent(launchStream, c->peekDone[k], 0));
             OKRT_HIP(c, hipMemcpyAsync(c->front[k].ptr, c->result, bytes, hipMemcpyDeviceToDevice, launchStream));
             OKRT_HIP(c, hipEventRecord(c->frontReady[k], launchStream));
+            // the next set's accumulation (possibly on another stream) rewrites c->result: it must come after this copy too, not
+            // only after this set's accumulation, or the peek could show a torn picture
+            if (pipelined) OKRT_HIP(c, hipEventRecord(c->accumDone[c->pipeLast], launchStream));
             c->frontValid[k] = true;
             c->frontFrames[k] = c->launchedFrames;
             c->frontNext = k ^ 1u;
@@ -1076,6 +1114,28 @@ okrt_status okrt_get_interval_ms(okrt_ctx* c, float* out_ms, uint32_t capacity, 
         *out_frames += f.frames;
     }
     return OKRT_OK;
+}
+
+// Test hook (not in okrt.h; needs no GPU): the launch sets `frames` consecutive frames of a progressive accumulation are issued as on
+// a context that owns tile_rows x width pixels — out[2k] = frames of set k, out[2k+1] = 1 when it rides the pipeline slots. Returns the
+// number of sets (those beyond `cap` pairs are counted, not written). pipeline_max_frames = 0: pipelining off; split_rays = 0: the default.
+uint32_t okrt_debug_launch_plan(uint32_t tile_rows, uint32_t width, uint32_t frames, uint32_t batch_limit, uint32_t pipeline_max_frames,
+                                uint64_t split_rays, uint32_t* out, uint32_t cap) {
+    const LaunchPlanParams p{tile_rows, width, std::max(1u, std::min(batch_limit, kMaxFramesPerLaunch)), pipeline_max_frames, kPipelineSlots, 2u,
+                             split_rays ? split_rays : kPipelineSplitRays, pipeline_max_frames != 0, true};
+    LaunchCursor lc;
+    uint32_t sets = 0;
+    while (frames) {
+        const LaunchStep st = nextLaunch(p, lc, frames);
+        if (out && sets < cap) {
+            out[2 * sets] = st.frames;
+            out[2 * sets + 1] = ridesSlots(p, st) ? 1u : 0u;
+        }
+        ++sets;
+        frames -= st.frames;
+        launched(lc, st.frames);
+    }
+    return sets;
 }
 
 okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats) {

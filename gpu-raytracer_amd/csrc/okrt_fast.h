@@ -149,6 +149,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
 LaunchStatus fastReserve(FastScene& fs, const SceneView& s, const TileView& t, uint32_t frames, uint32_t slot, bool frameSlots, hipStream_t stream, std::string& err);
 constexpr uint32_t kMaxFramesPerLaunch = 64;
 constexpr uint32_t kPipelineSlots = 4;  // launch sets that may be in flight together (queue slots = streams)
+constexpr uint64_t kPipelineSplitRays = 12ull << 20;  // a larger set of more than kPipelineDefaultFrames frames is issued as sub-sets on the slots when it traces at most this many camera rays
 constexpr uint32_t kPipelineMaxFrames = 32, kPipelineDefaultFrames = 4;  // OKRT_OPT_PIPELINE: launch sets up to n frames alternate between the two queue slots
 
 }  // namespace okrt

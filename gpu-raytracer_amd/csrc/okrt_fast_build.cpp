@@ -281,8 +281,9 @@ struct Emitter {
             const float* l = &cost[4 * (size_t)nd.left];
             const float* r = &cost[4 * (size_t)nd.right];
             float best = kInfCost;
+            ch[1] = 2;  // (boxes with extents around 1e19 overflow every sum to inf: no candidate is < best, and forest() must still get a split in 1..3)
             for (int i = 1; i <= 3; ++i) {  // a wide node here: i children from the left half, 4 - i from the right
-                const float v = l[i] + r[4 - i];
+                const float v = std::min(l[i] + r[4 - i], kInfCost);
                 if (v < best) {
                     best = v;
                     ch[1] = (uint8_t)i;
@@ -311,6 +312,10 @@ struct Emitter {
             return;
         }
         const uint8_t k = choice[4 * (size_t)n + i];
+        if (i < 1 || i > 3 || k >= i || count >= 4) {  // cannot happen with the tables solve() fills; a malformed table must not recurse or overrun kids[4]
+            if (count < 4) out[count++] = n;
+            return;
+        }
         if (k == 0) forest(n, i - 1, out, count);
         else {
             forest(nd.left, k, out, count);

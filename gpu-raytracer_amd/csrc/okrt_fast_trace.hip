@@ -96,7 +96,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             if (sp < (uint32_t)kLdsStack) e = sStack[sp][tid];
 #endif
             else e = myOverflow[sp - kLdsStack];
-            if (__uint_as_float(e.y) < best) return e.x;
+            // (e.x != kDone: an EMPTY child slot can be entered — and pushed — when its inverted box collapses under rounding on all
+            // three axes, a tiny node seen from far away by a ray through its grid origin; kEmptyRef == kDone would end the ray here)
+            if (__uint_as_float(e.y) < best && e.x != kDone) return e.x;
         }
         return kDone;
     };
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                                           fma_((float)((nearZ >> (8 * k)) & 255u), Az, Bz));
                 const float tfar = fminf(fminf(fma_((float)((farX >> (8 * k)) & 255u), Ax, Bx), fma_((float)((farY >> (8 * k)) & 255u), Ay, By)),
                                          fma_((float)((farZ >> (8 * k)) & 255u), Az, Bz));
-                const bool hit = tfar >= tnear && tfar > 0.f && tnear < best;  // (empty slots carry an inverted box: never entered)
+                const bool hit = tfar >= tnear && tfar > 0.f && tnear < best;  // (empty slots carry an inverted box: entered only in the corner case popNext filters)
                 tn[k] = hit ? tnear : kFltMax;  // kFltMax doubles as "miss" (never < best)
             }
             // sort the four (distance, child) pairs ascending: 5-comparator network, select-based (no branches)
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                     }
                 }
             }
-            cur = n ? ch[0] : popNext();
+            cur = (n && ch[0] != kDone) ? ch[0] : popNext();  // (ch[0] == kDone: the empty slot of the comment in popNext, as the nearest "hit")
             parkLeaf();
         }
         if (stepTri) {  // Moeller-Trumbore on triangle triJ of the parked leaf

@@ -453,7 +453,8 @@ okrt_status okrt_mgpu_reduce_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* 
     }
     if (!ncclOk(comms[0], rccl().GroupStart(), "ncclGroupStart")) return ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
     for (uint32_t k = 0; k < n && st == OKRT_OK; ++k)
-        if (hipSetDevice(p.fr[k].device) != hipSuccess || !ncclOk(comms[k], rccl().Reduce(p.fr[k].accum, k == p.rootSlot ? (void*)dst : nullptr, px * 4, ncclFloat, ncclSum, (int)root, comms[k]->comm, p.fr[k].stream), "ncclReduce"))
+        if (hipSetDevice(p.fr[k].device) != hipSuccess) st = ctxFail(ctxs[k], OKRT_ERR_DEVICE, "mgpu reduce: hipSetDevice(" + std::to_string(p.fr[k].device) + ") failed");
+        else if (!ncclOk(comms[k], rccl().Reduce(p.fr[k].accum, k == p.rootSlot ? (void*)dst : nullptr, px * 4, ncclFloat, ncclSum, (int)root, comms[k]->comm, p.fr[k].stream), "ncclReduce"))
             st = ctxFail(ctxs[k], OKRT_ERR_DEVICE, comms[k]->err);
     if (!ncclOk(comms[0], rccl().GroupEnd(), "ncclGroupEnd") && st == OKRT_OK) st = ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
     return st;

@@ -299,6 +299,10 @@ struct okrt_ctx {  // the oracle's context (same opaque name as the product's; s
     std::vector<uint32_t> bbImage, triImage;  // per-pixel counters of the last render
     int maxBounces = 1;
     int threads = 0;  // 0 = hardware_concurrency
+    // SENSITIVITY MODELS of the unpinned D3D11 sampler (okrt_oracle_set_sampler_model; tests/test_sampler_sensitivity.py): how far
+    // can the picture move if the hardware filters with fixed-point weights and across cube edges? Never on by default.
+    int samplerWeightBits = 0;   // 0 = exact fp32 weights; n = bilinear weights snapped to n fractional bits (D3D11 requires >= 8)
+    bool seamlessCube = false;   // bilinear footprints that leave a cube face take their texels from the adjacent face
     bool countersOn = false;
     Counters counters;
     std::string err;
@@ -335,6 +339,12 @@ inline bool isValidIdx(uint32_t idx) { return idx != UINT_MAX_U; }
 // lerp(t01,t11,fx), fy), WRAP addressing per RayTracer.cpp:99-109, slice = round-half-even(idx)
 // clamped to the array, non-finite coordinates sample as 0.
 inline V3 texel(const uint8_t* p) { return {p[0] / 255.f, p[1] / 255.f, p[2] / 255.f}; }
+// sensitivity model: a bilinear weight as fixed point with `bits` fractional bits (round to nearest; 1.0 stays representable)
+inline float snapWeight(float w, int bits) {
+    if (bits <= 0) return w;
+    const float s = (float)(1 << bits);
+    return floorf(fma_(w, s, 0.5f)) / s;
+}
 inline int wrapi(int i, int n) {
     int r = i % n;
     return r < 0 ? r + n : r;
@@ -349,7 +359,7 @@ V3 sampleTexture(const okrt_ctx& c, uint32_t textureIdx, float u, float v, Count
     const int W = (int)c.texW, H = (int)c.texH;
     float x = fma_(u, (float)W, -0.5f), y = fma_(v, (float)H, -0.5f);
     float fx0 = floorf(x), fy0 = floorf(y);
-    float fx = x - fx0, fy = y - fy0;
+    float fx = snapWeight(x - fx0, c.samplerWeightBits), fy = snapWeight(y - fy0, c.samplerWeightBits);
     // wrap in float first so huge coordinates stay in int range
     float wx = fx0 - floorf(fx0 / (float)W) * (float)W;
     float wy = fy0 - floorf(fy0 / (float)H) * (float)H;
@@ -365,12 +375,9 @@ V3 sampleTexture(const okrt_ctx& c, uint32_t textureIdx, float u, float v, Count
 // (z wins ties, then y); face coordinates are the D3D/GL table; bilinear with clamp-to-edge
 // inside the face (D3D10+ hardware filters seamlessly across edges: differs only within half a
 // texel of a face border; covered by the image tolerance).
-V3 getEnvironmentLight(const okrt_ctx& c, V3 d, Counters& cnt) {
-    cnt.env_taps++;
-    if (c.envFace == 0) return {0, 0, 0};
+// major axis / face / face coordinates of a direction (the D3D / GL table; z wins ties, then y)
+inline void cubeFace(V3 d, int& face, float& sc, float& tc, float& ma) {
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    int face;
-    float sc, tc, ma;
     if (az >= ax && az >= ay) {
         ma = az;
         if (d.z >= 0) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; }
@@ -381,13 +388,50 @@ V3 getEnvironmentLight(const okrt_ctx& c, V3 d, Counters& cnt) {
         ma = ax;
         if (d.x >= 0) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; }
     }
+}
+// Sensitivity model (seamlessCube): texel (x, y) of `face`, where x or y may lie one texel outside the face — then the texel of the
+// ADJACENT face that the direction through that texel centre falls on (what seamless hardware filtering reads; at a cube corner
+// hardware averages the three faces' corner texels, this takes one of them).
+V3 cubeTexelSeamless(const okrt_ctx& c, int face, int x, int y) {
+    const int F = (int)c.envFace;
+    if (x < 0 || x >= F || y < 0 || y >= F) {
+        const float sc = (2.f * ((float)x + 0.5f)) / (float)F - 1.f, tc = (2.f * ((float)y + 0.5f)) / (float)F - 1.f;
+        V3 d;
+        switch (face) {  // inverse of the table in cubeFace with ma = 1
+            case 0: d = v3(1.f, -tc, -sc); break;
+            case 1: d = v3(-1.f, -tc, sc); break;
+            case 2: d = v3(sc, 1.f, tc); break;
+            case 3: d = v3(sc, -1.f, -tc); break;
+            case 4: d = v3(sc, -tc, 1.f); break;
+            default: d = v3(-sc, -tc, -1.f); break;
+        }
+        float s2, t2, ma;
+        cubeFace(d, face, s2, t2, ma);
+        x = std::clamp((int)floorf(fma_(s2 / ma, 0.5f, 0.5f) * (float)F), 0, F - 1);
+        y = std::clamp((int)floorf(fma_(t2 / ma, 0.5f, 0.5f) * (float)F), 0, F - 1);
+    }
+    return texel(c.env.data() + ((size_t)face * F * F + (size_t)y * F + x) * 4);
+}
+
+V3 getEnvironmentLight(const okrt_ctx& c, V3 d, Counters& cnt) {
+    cnt.env_taps++;
+    if (c.envFace == 0) return {0, 0, 0};
+    int face;
+    float sc, tc, ma;
+    cubeFace(d, face, sc, tc, ma);
     float u = fma_(sc / ma, 0.5f, 0.5f), v = fma_(tc / ma, 0.5f, 0.5f);
     if (!std::isfinite(u)) u = 0.f;
     if (!std::isfinite(v)) v = 0.f;
     const int F = (int)c.envFace;
     float x = fma_(u, (float)F, -0.5f), y = fma_(v, (float)F, -0.5f);
     float fx0 = floorf(x), fy0 = floorf(y);
-    float fx = x - fx0, fy = y - fy0;
+    float fx = snapWeight(x - fx0, c.samplerWeightBits), fy = snapWeight(y - fy0, c.samplerWeightBits);
+    if (c.seamlessCube) {
+        const int xi = (int)fx0, yi = (int)fy0;
+        V3 t00 = cubeTexelSeamless(c, face, xi, yi), t10 = cubeTexelSeamless(c, face, xi + 1, yi);
+        V3 t01 = cubeTexelSeamless(c, face, xi, yi + 1), t11 = cubeTexelSeamless(c, face, xi + 1, yi + 1);
+        return lerp(lerp(t00, t10, fx), lerp(t01, t11, fx), fy);
+    }
     int x0 = std::clamp((int)fx0, 0, F - 1), x1 = std::clamp((int)fx0 + 1, 0, F - 1);
     int y0 = std::clamp((int)fy0, 0, F - 1), y1 = std::clamp((int)fy0 + 1, 0, F - 1);
     const uint8_t* base = c.env.data() + (size_t)face * F * F * 4;
@@ -825,6 +869,14 @@ okrt_status okrt_oracle_set_option(okrt_ctx* c, okrt_option opt, int64_t value) 
         case OKRT_OPT_QUEUE_MEMORY_MB: return OKRT_OK;
         default: return fail(c, OKRT_ERR_INVALID_ARG, "unknown option");
     }
+}
+// Oracle-only: the two sensitivity models of the unpinned D3D11 sampler (see okrt_ctx). weight_fraction_bits = 0 and seamless_cube = 0
+// restore the oracle's defaults (exact fp32 weights, clamp inside the face).
+okrt_status okrt_oracle_set_sampler_model(okrt_ctx* c, int weight_fraction_bits, int seamless_cube) {
+    if (!c || weight_fraction_bits < 0 || weight_fraction_bits > 23) return OKRT_ERR_INVALID_ARG;
+    c->samplerWeightBits = weight_fraction_bits;
+    c->seamlessCube = seamless_cube != 0;
+    return OKRT_OK;
 }
 okrt_status okrt_oracle_set_threads(okrt_ctx* c, int threads) {
     if (!c || threads < 0) return OKRT_ERR_INVALID_ARG;

@@ -90,3 +90,22 @@ def test_fast_structure_degenerate_inputs(oracle):
         dist, tri, inst, stats, T = fast_closest(rt, np.array([[1.0, 1.0, 0.0], [9.0, 9.0, 0.0]]), np.array([[0, 0, 1.0], [0, 0, 1.0]]))
         assert stats[1] == len(soup) and dist[0] == 5.0 and dist[1] > 3e38
         rt.close()
+
+
+def test_fast_structure_with_coordinates_that_overflow_the_collapse_costs(oracle):
+    """Boxes with extents around 1e19 have areas around 1e38: every sum in the SAH-optimal collapse (okrt_fast_build.cpp:
+    Emitter::solve) overflows to inf, no candidate split is ever "cheaper", and the forest walk must still terminate with at
+    most four children per node (a malformed OBJ or table can supply such numbers; runs under `make asan` too)."""
+    rng = np.random.default_rng(5)
+    centres = rng.uniform(-1e19, 1e19, (400, 1, 3))
+    soup = (centres + rng.uniform(-3e18, 3e18, (400, 3, 3))).astype(np.float32)
+    soup[:8] *= np.float32(1e-19)  # and a few ordinary triangles among them
+    desc = scenes.SceneDescription("huge")
+    desc.meshes = [(soup, np.zeros((len(soup), 33), np.float32))]
+    desc.entities = [scenes.MeshEntity(0, {})]
+    rt, sc, res = oracle.instantiate(desc, 16, 16)
+    orig = np.zeros((3, 3))
+    dist, tri, inst, stats, T = fast_closest(rt, orig, np.array([[0, 0, 1.0], [1.0, 0, 0], [0, 1.0, 0]]))
+    assert stats[1] == len(soup) and stats[0] >= 1  # every triangle referenced, a tree came out
+    assert np.isfinite(dist[dist < 3e38]).all()
+    rt.close()

@@ -350,17 +350,17 @@ def test_launch_sets_shrink_when_the_allocator_says_no():
 
 
 def test_interval_ms_only_sums_launch_sets_of_the_newest_shape():
-    """okrt_get_interval_ms: 100 frames = 64 + 36; the 36-frame set is the newest, so exactly one launch set of 36 frames
-    is reported (a mixed sum would describe a fictitious 50-frame launch)."""
+    """okrt_get_interval_ms: 100 frames = 64 + 36, on a frame this small issued as sub-sets of 32, 32, 18 and 18; the 18-frame
+    shape is the newest, so exactly those two launches are reported (a mixed sum would describe a fictitious 25-frame launch)."""
     desc = scenes.small_mesh_scene(seed=4, n_objects=4, detail=6)
     rt, sc, res = scenes.instantiate(desc, 128, 72)
     rt.ctx.set_option(abi.OPT_TIMING, 16)
     rt.renderFrames(100)
     ms, launches, frames = rt.ctx.interval_ms()
-    assert (launches, frames) == (1, 36) and len(ms) == 4 and all(m >= 0 for m in ms)
+    assert (launches, frames) == (2, 36) and len(ms) == 4 and all(m >= 0 for m in ms)
     rt.renderFrames(64)
     ms, launches, frames = rt.ctx.interval_ms()
-    assert (launches, frames) == (2, 128)
+    assert (launches, frames) == (4, 128)
     rt.close()
 
 
@@ -452,6 +452,63 @@ def test_peek_shows_a_resolved_picture_without_executing_deferred_frames():
     rt.close()
 
 
+def test_peek_between_pipelined_launch_sets_is_never_torn():
+    """Launch sets that ride the pipeline slots only order their accumulation kernels; the copy a peek reads is made after a set's
+    accumulation on that set's stream, and the NEXT set's accumulation — another stream — rewrites the resolved picture. It must wait
+    for the copy as well (round 3 did not order the two): every peeked picture is the exact resolve of some earlier frame count."""
+    desc = scenes.small_mesh_scene(seed=6, n_objects=5, detail=8, with_lights=True)
+    W, H = 640, 360
+    sizes = [1, 2, 4, 3, 1, 1, 4, 2, 5, 10, 1, 3] * 4  # (5 and 10: issued as sub-sets, which ride the slots too)
+    ref, _, _ = scenes.instantiate(desc, W, H)
+    ref.ctx.set_option(abi.OPT_DEFER, 0)
+    ref.ctx.set_option(abi.OPT_PIPELINE, 0)
+    pictures = {0: np.zeros((H, W, 4), np.uint8)}
+    for k in range(1, sum(sizes) + 1):
+        ref.render()
+        pictures[k] = ref.ctx.read_result().copy()
+    ref.close()
+    rt, sc, res = scenes.instantiate(desc, W, H)
+    rt.ctx.set_option(abi.OPT_DEFER, 0)
+    rt.ctx.set_option(abi.OPT_PIPELINE, 4)
+    rt.ctx.peek_result()  # from now on every launch set leaves a copy behind
+    done, last, moved = 0, 0, 0
+    for m in sizes:
+        rt.renderFrames(m) if m > 1 else rt.render()
+        done += m
+        img, n = rt.ctx.peek_result()
+        assert last <= n <= done, (done, n, last)
+        assert np.array_equal(img, pictures[n]), (done, n)
+        moved += n > last
+        last = n
+    assert moved >= 8  # the peeks really saw sets finish while others were in flight
+    assert np.array_equal(rt.ctx.read_result(), pictures[done])
+    rt.close()
+
+
+def test_sub_sets_of_a_small_tile_are_bit_identical_to_one_set():
+    """okrt_render_frames on a small tile (one rank's stripes) issues a launch set as two sub-sets on the pipeline slots
+    (csrc/okrt_launch_plan.h); framebuffers are the ones a single set — and single frames — produce, bit for bit."""
+    desc = scenes.small_mesh_scene(seed=9, n_objects=6, detail=9, with_lights=True)
+
+    def run(pipeline, chunks):
+        rt, sc, res = scenes.instantiate(desc, 384, 216)
+        rt.ctx.set_tile(8, 3, 8)  # rank 3 of an 8-way split
+        rt.ctx.set_option(abi.OPT_PIPELINE, pipeline)
+        rt.ctx.set_option(abi.OPT_DEFER, 0)
+        for m in chunks:
+            rt.renderFrames(m)
+        acc, img = rt.ctx.read_accum().copy(), rt.ctx.read_result().copy()
+        rt.close()
+        return acc, img
+
+    a = run(4, [20, 21, 64, 5])
+    b = run(0, [20, 21, 64, 5])
+    c = run(0, [1] * 110)
+    assert (a[0][..., 3] == 110).all()
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], c[0], equal_nan=True) and np.array_equal(a[1], c[1])
+
+
 def test_two_launch_sets_in_flight_are_bit_identical_to_one_at_a_time():
     """OKRT_OPT_PIPELINE: consecutive launch sets alternate between two queue slots and two streams and only their
     accumulation kernels are ordered. Whatever the host does in between — single frames, batches of every size (40 frames
@@ -524,7 +581,37 @@ def test_a_deferring_render_reports_the_allocator_refusal_itself():
         rt.render()
     rt.ctx.synchronize()
     _, launches, frames = rt.ctx.interval_ms()
-    assert (launches, frames) == (2, 16)  # the remembered limit: sets of 8
+    assert (launches, frames) == (4, 16)  # the remembered limit: sets of 8, each issued as two sub-sets of 4 on this small frame
+    rt.close()
+
+
+def test_a_small_deferral_reserves_the_slots_its_sets_will_ride():
+    """OKRT_OPT_DEFER <= OKRT_OPT_PIPELINE: the deferred sets take turns on the pipeline slots with frame slots, so that is what the
+    reservation allocates (round 3 reserved slot 0 in the other mode: the refusal then surfaced at whichever call flushed)."""
+    desc = scenes.small_mesh_scene(seed=4, n_objects=5, detail=10, with_lights=True)
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.ctx.set_option(abi.OPT_DEFER, 0)
+    for _ in range(14):
+        rt.render()
+    want = rt.ctx.read_accum().copy()
+    rt.close()
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.ctx.set_option(abi.OPT_DEFER, 4)
+    rt.render()
+    rt.ctx.set_option(abi.OPT_DEBUG_FAIL_ALLOC, 2)     # (executes the waiting frame, then arms the hook)
+    rt.render()
+    rt.render()                                        # second waiting frame: reserves sets of 4 on every slot -> refused -> sets of 2
+    rt.ctx.set_option(abi.OPT_DEBUG_FAIL_ALLOC, 0)     # (a refusal that had been left for a later flush would fire here or below)
+    for _ in range(11):
+        rt.render()
+    got = rt.ctx.read_accum()
+    assert np.array_equal(got, want, equal_nan=True) and (got[..., 3] == 14).all()
+    rt.ctx.set_option(abi.OPT_TIMING, 8)
+    for _ in range(8):
+        rt.render()
+    rt.ctx.synchronize()
+    _, launches, frames = rt.ctx.interval_ms()
+    assert (launches, frames) == (4, 8)  # the remembered limit: sets of 2
     rt.close()
 
 
@@ -537,6 +624,11 @@ def test_a_granted_reservation_leaves_larger_launch_sets_alone():
     for _ in range(40):
         rt.render()
     rt.ctx.synchronize()
+    rt.ctx.set_option(abi.OPT_TIMING, 8)
+    rt.renderFrames(64)
+    _, launches, frames = rt.ctx.interval_ms()
+    assert (launches, frames) == (2, 64)  # one set of 64 frames; on a frame this small it is issued as two sub-sets of 32
+    rt.ctx.set_option(abi.OPT_PIPELINE, 0)
     rt.ctx.set_option(abi.OPT_TIMING, 8)
     rt.renderFrames(64)
     _, launches, frames = rt.ctx.interval_ms()

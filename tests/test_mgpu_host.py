@@ -7,6 +7,7 @@ import multiprocessing as mp
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -61,9 +62,16 @@ def _store_rank(rank, world, key, root, out):
     own_mask = m.settle_shared_devices(m.launch_plan(1, dict(env, HIP_VISIBLE_DEVICES=str(rank)), 1), st, dict(env, HIP_VISIBLE_DEVICES=str(rank)))
     no_mask = m.settle_shared_devices(m.launch_plan(1, env, 8), st, env)
     crowded = m.settle_shared_devices(m.launch_plan(1, env, 2), st, env)  # 3 ranks, 2 GPUs: ranks 0 and 2 on device 0
+    # the barrier that brackets a timed region: nobody leaves before the last rank arrived, and all leave together
+    stamps = []
+    for k in range(5):
+        time.sleep(0.003 * ((rank + k) % world))  # staggered arrivals
+        arrive = time.monotonic()  # (CLOCK_MONOTONIC: one clock for every process of the machine)
+        st.tight_barrier()
+        stamps.append((arrive, time.monotonic()))
     st.close()
     out.put((rank, [len(g) for g in got], [g[:1] for g in got], len(blob), total,
-             (box_mask["rehearsal"], own_mask["rehearsal"], no_mask["rehearsal"], crowded["rehearsal"])))
+             (box_mask["rehearsal"], own_mask["rehearsal"], no_mask["rehearsal"], crowded["rehearsal"]), stamps))
 
 
 def test_file_store_allgather_barrier_close(tmp_path):
@@ -77,9 +85,18 @@ def test_file_store_allgather_barrier_close(tmp_path):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, lens, firsts, blob, total, shared in res:
+    for rank, lens, firsts, blob, total, shared, stamps in res:
         assert lens == [1, 2, 3] and firsts == [b"\x00", b"\x01", b"\x02"] and blob == 128 and total == 6
         assert shared == (True, False, False, True)
+    for k in range(5):
+        arrive = [r[6][k][0] for r in res]
+        leave = [r[6][k][1] for r in res]
+        assert min(leave) >= max(arrive)  # nobody left before the last rank arrived
+        # all leave together: microseconds on an idle machine; the bound allows for a loaded 8-core CI container (the file-polling
+        # barrier it replaces in front of bench.py's timed region let early arrivals sleep up to 2 ms between looks)
+        assert max(leave) - min(leave) < 0.02, (k, leave)
+    skews = sorted(max(r[6][k][1] for r in res) - min(r[6][k][1] for r in res) for k in range(5))
+    print("tight barrier exit skew (s), 5 rounds:", ["%.6f" % s for s in skews])
     assert not [d for d in os.listdir(tmp_path) if d.startswith("okrt_rdzv_")]  # rank 0 removed the directory
 
 
