@@ -168,6 +168,8 @@ void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const Sc
 void launchSetRenderData(hipStream_t stream, const okrt_render_data& rd, okrt_render_data* dst);
 void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t pixels, uint32_t frames, const float4* radiance, float4* accum,
                       uint32_t* result);
+// diagnostic (OKRT_FAST_SORT, okrt_fast_sort.hip): `dst` = the rays of `src` fully sorted by coherence key inside each shard
+bool sortQueue(uint32_t slot, uint32_t mode, hipStream_t stream, const uint4* nodes, RayQueue src, RayQueue dst, const ShardView& sv, uint32_t items, std::string& err);
 void launchFastKat(hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats,
                    float* out, uint32_t outFloats);
 

@@ -241,7 +241,8 @@ LaunchStatus ensureQueues(FastScene& fs, FastScene::LaunchSlot& ls, const SceneV
     // 132 bytes per ray and frame in flight. Per pixel and frame of a multi-frame set: a 16-byte radiance slot.
     static const bool envPacket0 = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused0 = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
-    const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2;
+    static const uint32_t envSort0 = getenv("OKRT_FAST_SORT") ? (uint32_t)atoi(getenv("OKRT_FAST_SORT")) : 0u;  // diagnostic: sorted copy of queue 1 lives in queue 0
+    const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2 || envSort0;
     const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 || frameSlots ? (size_t)t.rows * t.W * frames * 16 : 0);
     if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
         err = "launch set exceeds the queue memory budget";
@@ -338,6 +339,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     mark();
     static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
+    static const uint32_t envSort = getenv("OKRT_FAST_SORT") ? (uint32_t)atoi(getenv("OKRT_FAST_SORT")) : 0u;
     const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
     const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
@@ -356,6 +358,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
         launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, fa);
         mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
+        if (envSort && lastBounce == 1 && !sortQueue(order.slot, envSort, stream, fs.nodes.p, ls.q[1], ls.q[0], shards(1, false), (uint32_t)items, err)) return LaunchStatus::Device;
     } else {
         // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
         launchGenerate(sg, stream, rd, t, ls.q[0], perFrame, frames);
@@ -369,7 +372,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     mark();
     // segments 1..lastBounce: queue b lives in q[b & 1]
     for (uint32_t b = 1; b <= lastBounce; ++b) {
-        RayQueue& qin = ls.q[b & 1];
+        RayQueue& qin = (envSort && lastBounce == 1 && packet && envFused) ? ls.q[0] : ls.q[b & 1];  // (diagnostic: the sorted copy)
         RayQueue& qout = ls.q[(b + 1) & 1];
         launchTrace(cnt, tg, stream, fv, s, rd, t, qin, ls.hb, shards(b, false), 0u, counters, rayTotals);
         mark();

@@ -192,10 +192,10 @@ def test_config4_sponza_1080p_three_frames_batched_vs_oracle(oracle, sponza_desc
 def test_config4_1080p_1024spp_vs_oracle(oracle, sponza_desc):
     """BASELINE.json's config 4 at its LITERAL size: 1920x1080, 1024 spp of progressive accumulation on the full
     sponza-proxy, one render() per frame like the reference's main loop (Application.cpp:106-128; the library defers and
-    batches them). The oracle renders the same 1024 frames on every 135th row (8 rows spread over the picture; seeds
+    batches them). The oracle renders the same 1024 frames on every 45th row (24 rows = 46 080 pixels spread over the picture; seeds
     depend on global x, y, W and the frame index only). N >= 256 rule of SURVEY 8c: per-pixel L2 of acc / N <= 4/255 for
     >= 99.9 % of the pixels, RMSE <= 1/255; and every pixel of the WHOLE frame received every frame."""
-    W, H, N, K = 1920, 1080, 1024, 135
+    W, H, N, K = 1920, 1080, 1024, 45
     rt, sc, res = scenes.instantiate(sponza_desc, W, H)
     for _ in range(N):
         rt.render()
@@ -210,7 +210,7 @@ def test_config4_1080p_1024spp_vs_oracle(oracle, sponza_desc):
     ca, cr = ort.ctx.read_accum(), ort.ctx.read_result()
     ort.close()
     g, c = ga[::K, :, :3].astype(np.float64) / N, ca[..., :3].astype(np.float64) / N
-    assert g.shape == c.shape == (8, W, 3)
+    assert g.shape == c.shape == (H // K, W, 3)
     fin = np.isfinite(g).all(-1) & np.isfinite(c).all(-1)
     assert (np.isfinite(g).all(-1) == np.isfinite(c).all(-1)).all()
     l2 = np.sqrt(((g - c) ** 2).sum(-1))
@@ -351,7 +351,8 @@ def assert_outliers_are_explained(desc, acc_fast, acc_oracle, W, H, max_bounces=
     bit-identical (distance or triangle) on some segment; and the budget such pixels may use is 2 % of the frame, with
     RMSE <= 0.02 over all pixels as in the rule."""
     frac, rmse, nanmm, l2 = compare_accum(acc_fast, acc_oracle)
-    assert rmse <= 0.04 and nanmm <= 1e-5, (rmse, nanmm)
+    print(f"explained-outlier comparison: rmse {rmse:.5f}, {int((~(l2 <= 1e-3)).sum())} pixels beyond 1e-3 of {W * H}")
+    assert rmse <= 0.02 and nanmm <= 1e-5, (rmse, nanmm)
     ys, xs = np.nonzero(~(l2 <= 1e-3))
     assert len(ys) <= 0.02 * W * H, (len(ys), W * H)
     if not len(ys):
