@@ -56,6 +56,9 @@ WORKLOADS = {
     "sponza": ("sponza_proxy", {}, 1920, 1080, "sponza-proxy 262267 tris/390 meshes/26 tex, 1920x1080, 1 spp/frame, NUM_BOUNCES=1"),
     "sponza4k": ("sponza_proxy", {}, 3840, 2160, "sponza-proxy 262267 tris/390 meshes/26 tex, 3840x2160, 1 spp/frame, NUM_BOUNCES=1"),
     "dragon": ("dragon_proxy", {"num_triangles": 871414}, 1280, 720, "dragon-proxy 871414 tris, diffuse, 1280x720"),
+    # beyond the 256 MiB Infinity Cache: 384 MB of Tri48 + 40 MB of Node4Q (+ 512 MB of shading records): the one workload whose
+    # fabric-side bytes are HBM bytes
+    "dragon8m": ("dragon_proxy", {"num_triangles": 8000000}, 1280, 720, "dragon-proxy 8000000 tris, diffuse, 1280x720 (structure beyond the Infinity Cache)"),
     "dragon80k": ("dragon_proxy", {"num_triangles": 80000}, 1280, 720, "dragon-proxy 80000 tris, diffuse, 1280x720"),
     "glass": ("glass_revolver_proxy", {}, 1920, 1080, "glass + revolver-proxy + IBL, 1920x1080"),
     "spheres": ("test_scene_spheres", {}, 256, 256, "TestScene 4 spheres 256x256"),

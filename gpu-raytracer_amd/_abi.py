@@ -115,6 +115,7 @@ KAT_PCG_HASH, KAT_RANDOM_FLOAT, KAT_RAY_SPHERE, KAT_RAY_TRIANGLE, KAT_RAY_AABB, 
 KAT_RANDOM_VECTOR, KAT_REFLECTANCE, KAT_REFLECT_DIRECTION, KAT_TRANSPARENCY_BOUNCE, KAT_PRIMARY_RAY = range(10, 15)
 KAT_SEGMENT_RAY = 15
 KAT_IEEE_SHORTCUTS = 16
+KAT_CLOSEST_HIT_TRACE = 17
 HEADER_SYMBOLS = ["okrt_" + n for n in list(SIGNATURES) + list(PRODUCT_ONLY)]
 
 

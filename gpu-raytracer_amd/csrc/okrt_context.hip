@@ -1139,14 +1139,15 @@ uint32_t okrt_debug_launch_plan(uint32_t tile_rows, uint32_t width, uint32_t fra
 }
 
 okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats) {
-    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_IEEE_SHORTCUTS) return OKRT_ERR_INVALID_ARG;
-    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7, 1, 2, 8, 8, 62, 63, 2}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5, 4, 1, 4, 4, 7, 8, 4};
+    if (!c || !in || !out || !in_floats || !out_floats || (int)op < 0 || (int)op > OKRT_KAT_CLOSEST_HIT_TRACE) return OKRT_ERR_INVALID_ARG;
+    static const uint32_t needIn[] = {1, 1, 10, 15, 12, 7, 3, 3, 7, 7, 1, 2, 8, 8, 62, 63, 2, 7}, needOut[] = {2, 2, 1, 3, 1, 3, 3, 3, 6, 5, 4, 1, 4, 4, 7, 8, 4, 5};
     if (in_floats < needIn[op] || out_floats < needOut[op]) return fail(c, OKRT_ERR_INVALID_ARG, "kat: record too short for this probe");
     OKRT_FLUSH(c);
     OKRT_HIP(c, hipSetDevice(c->device));
-    if (op == OKRT_KAT_CLOSEST_HIT || op == OKRT_KAT_CLOSEST_HIT_FAST || op == OKRT_KAT_SEGMENT_RAY) {  // walks the uploaded tables: they must be consistent
+    const bool fastProbe = op == OKRT_KAT_CLOSEST_HIT_FAST || op == OKRT_KAT_CLOSEST_HIT_TRACE;
+    if (op == OKRT_KAT_CLOSEST_HIT || fastProbe || op == OKRT_KAT_SEGMENT_RAY) {  // walks the uploaded tables: they must be consistent
         okrt_status vs = ensureTables(c);
-        if (vs == OKRT_OK && op == OKRT_KAT_CLOSEST_HIT_FAST) vs = ensureFast(c);
+        if (vs == OKRT_OK && fastProbe) vs = ensureFast(c);
         if (vs != OKRT_OK) return vs;
     }
     if (!n) return OKRT_OK;
@@ -1157,8 +1158,12 @@ okrt_status okrt_debug_kat(okrt_ctx* c, okrt_kat op, uint32_t n, const float* in
     if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, (size_t)n * out_floats * sizeof(float), c->stream);
     if (e == hipSuccess) {
         std::string msg;
-        if (op == OKRT_KAT_CLOSEST_HIT_FAST) {
-            if (!fastKat(c->fast, makeView(c), n, dIn, in_floats, dOut, out_floats, c->stream, msg)) {
+        if (fastProbe) {
+            okrt_render_data rd{};
+            std::memcpy(&rd.numSpheres, &in[6], sizeof(uint32_t));  // (the bounce kernel takes it from RenderData: uniform over the probe)
+            rd.numSpheres = std::min(rd.numSpheres, c->tables[OKRT_TABLE_SPHERE].count);
+            if (!(op == OKRT_KAT_CLOSEST_HIT_FAST ? fastKat(c->fast, makeView(c), n, dIn, in_floats, dOut, out_floats, c->stream, msg)
+                                                  : fastKatTrace(c->fast, makeView(c), rd, n, dIn, in_floats, dOut, out_floats, c->stream, msg))) {
                 hipFree(dIn);
                 hipFree(dOut);
                 return fail(c, OKRT_ERR_STATE, "kat: " + msg);

@@ -119,6 +119,10 @@ void fastBuildInfo(const FastScene* scene, FastBuildInfo* info);
 // known-answer probe: closest hit of n rays through the structure, one thread per ray (okrt_debug_kat)
 bool fastKat(const FastScene* scene, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats,
              hipStream_t stream, std::string& err);
+// known-answer probe through traceKernel itself (OKRT_KAT_CLOSEST_HIT_TRACE): the rays go onto a sharded queue, one launch of the
+// persistent bounce-ray kernel traces them, the hit records come back in ray order
+bool fastKatTrace(FastScene* scene, const SceneView& s, const okrt_render_data& rd, uint32_t n, const float* in, uint32_t inFloats, float* out,
+                  uint32_t outFloats, hipStream_t stream, std::string& err);
 // upper bound for the wavefront queues of one launch set (0 = none): larger sets are refused and the caller halves them
 void fastSetQueueBudget(FastScene** scene, size_t bytes);
 // test hook (OKRT_OPT_DEBUG_FAIL_ALLOC): the nth queue allocation from now on reports out-of-memory

@@ -170,6 +170,8 @@ void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t p
                       uint32_t* result);
 // diagnostic (OKRT_FAST_SORT, okrt_fast_sort.hip): `dst` = the rays of `src` fully sorted by coherence key inside each shard
 bool sortQueue(uint32_t slot, uint32_t mode, hipStream_t stream, const uint4* nodes, RayQueue src, RayQueue dst, const ShardView& sv, uint32_t items, std::string& err);
+void launchKatQueue(hipStream_t stream, bool collect, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, RayQueue q, HitBuffer hb,
+                    uint32_t cap, uint32_t* counts);
 void launchFastKat(hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats,
                    float* out, uint32_t outFloats);
 

@@ -167,6 +167,51 @@ bool fastKat(const FastScene* fs, const SceneView& s, uint32_t n, const float* i
     return true;
 }
 
+bool fastKatTrace(FastScene* fs, const SceneView& s, const okrt_render_data& rd, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats,
+                  hipStream_t stream, std::string& err) {
+    if (!fs || !fs->nodes.p) {
+        err = "no structure built yet";
+        return false;
+    }
+    // its own small buffers (a probe must not disturb the launch slots): a / b arrays of the queue, hit records, one segment's
+    // shard counters and cursors, the spill slab, the two ray totals
+    const uint32_t cap = (((n + kShards - 1) / kShards + 255) / 256) * 256;
+    const size_t items = (size_t)cap * kShards;
+    RayQueue q{};
+    HitBuffer hb{};
+    uint32_t* counts = nullptr;
+    uint2* overflow = nullptr;
+    unsigned long long* totals = nullptr;
+    auto release = [&]() {
+        for (void* p : {(void*)q.a, (void*)q.b, (void*)hb.h, (void*)hb.tri, (void*)counts, (void*)overflow, (void*)totals})
+            if (p) hipFree(p);
+    };
+    const uint32_t countWords = 2 * kShards * kCursorStride;
+    bool ok = devAlloc(&q.a, items, err) && devAlloc(&q.b, items, err) && devAlloc(&hb.h, items, err) && devAlloc(&hb.tri, items, err) &&
+              devAlloc(&counts, countWords, err) && devAlloc(&overflow, (size_t)fs->traceBlocks * kTraceThreads * fs->overflowCap, err) && devAlloc(&totals, 2, err);
+    hipError_t e = hipSuccess;
+    if (ok) {
+        e = hipMemsetAsync(counts, 0, countWords * sizeof(uint32_t), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(hb.h, 0xFF, items * sizeof(float4), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(hb.tri, 0xFF, items * sizeof(uint32_t), stream);
+    }
+    if (ok && e == hipSuccess) {
+        launchKatQueue(stream, false, n, in, inFloats, out, outFloats, q, hb, cap, counts);
+        const FastView fv{fs->nodes.p, fs->tris.p, overflow, fs->overflowCap, (uint32_t)(fs->numNodes * sizeof(Node4Q)), (uint32_t)(fs->numTris * sizeof(Tri48))};
+        const ShardView sv{cap, 0u, kBatch, 1u, counts, counts + kShards * kCursorStride};
+        launchTrace(false, dim3(fs->traceBlocks), stream, fv, s, rd, TileView{}, q, hb, sv, 0u, nullptr, totals);
+        launchKatQueue(stream, true, n, in, inFloats, out, outFloats, q, hb, cap, counts);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the buffers are released below
+    }
+    release();
+    if (ok && e != hipSuccess) {
+        err = std::string("trace probe: ") + hipGetErrorString(e);
+        ok = false;
+    }
+    return ok;
+}
+
 void fastDebugFailAlloc(int nth) { g_failAllocIn = nth; }
 
 void fastSetQueueBudget(FastScene** scene, size_t bytes) {

@@ -7,6 +7,9 @@
 #ifndef OKRT_ASM_POP
 #define OKRT_ASM_POP 1
 #endif
+#ifndef OKRT_TRACE_EMPTY_GUARD
+#define OKRT_TRACE_EMPTY_GUARD 1  // 0 = round 3's kernel, for showing that test_an_empty_child_slot_that_collapses... fails without the guard
+#endif
 
 namespace okrt {
 namespace fastdetail {
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             else e = myOverflow[sp - kLdsStack];
             // (e.x != kDone: an EMPTY child slot can be entered — and pushed — when its inverted box collapses under rounding on all
             // three axes, a tiny node seen from far away by a ray through its grid origin; kEmptyRef == kDone would end the ray here)
-            if (__uint_as_float(e.y) < best && e.x != kDone) return e.x;
+            if (__uint_as_float(e.y) < best && (!OKRT_TRACE_EMPTY_GUARD || e.x != kDone)) return e.x;
         }
         return kDone;
     };
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                     }
                 }
             }
-            cur = (n && ch[0] != kDone) ? ch[0] : popNext();  // (ch[0] == kDone: the empty slot of the comment in popNext, as the nearest "hit")
+            cur = (n && (!OKRT_TRACE_EMPTY_GUARD || ch[0] != kDone)) ? ch[0] : popNext();  // (ch[0] == kDone: the empty slot of the comment in popNext, as the nearest "hit")
             parkLeaf();
         }
         if (stepTri) {  // Moeller-Trumbore on triangle triJ of the parked leaf
@@ -717,7 +720,35 @@ __global__ __launch_bounds__(64) void fastKatKernel(const uint4* __restrict__ no
     o[4] = __uint_as_float(hitTri);
 }
 
+// OKRT_KAT_CLOSEST_HIT_TRACE: ray i of the probe sits at queue position (i % kShards) * cap + i / kShards, so every shard (and the
+// stealing between them) takes part; `collect` = false fills the queue and the shard counts, true copies the hit records back
+__global__ __launch_bounds__(256) void katQueueKernel(bool collect, uint32_t n, const float* __restrict__ in, uint32_t inFloats, float* __restrict__ out,
+                                                     uint32_t outFloats, RayQueue q, HitBuffer hb, uint32_t cap, uint32_t* counts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (!collect && i < kShards) counts[i * kCursorStride] = (n + kShards - 1 - i) / kShards;
+    if (i >= n) return;
+    const uint32_t pos = (i % kShards) * cap + i / kShards;
+    if (!collect) {
+        const float* a = in + (size_t)i * inFloats;
+        q.a[pos] = make_float4(a[0], a[1], a[2], a[3]);
+        q.b[pos] = make_float4(a[4], a[5], 0.f, __uint_as_float(i));
+    } else {
+        const float4 h = hb.h[pos];
+        float* o = out + (size_t)i * outFloats;
+        o[0] = h.x;
+        o[1] = __uint_as_float(__float_as_uint(h.w) != kInvalid ? 1u : 0u);
+        o[2] = 0.f;
+        o[3] = h.w;
+        o[4] = __uint_as_float(hb.tri[pos]);
+    }
+}
+
 }  // namespace
+
+void launchKatQueue(hipStream_t stream, bool collect, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, RayQueue q, HitBuffer hb,
+                    uint32_t cap, uint32_t* counts) {
+    hipLaunchKernelGGL(katQueueKernel, dim3((std::max(n, kShards) + 255) / 256), dim3(256), 0, stream, collect, n, in, inFloats, out, outFloats, q, hb, cap, counts);
+}
 
 void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
                  RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals) {

@@ -15,6 +15,8 @@ RayTracer objects of the host layer (any device backend).
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 
 F32 = np.float32
@@ -83,14 +85,18 @@ def grid_surface(pos_fn, nu, nv, uv_scale=(1.0, 1.0), flip=False):
     i, j = i.ravel(), j.ravel()
     quads = [(i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)]
     tri_idx = [(0, 1, 2), (0, 2, 3)]
-    pos = np.empty((2 * nu * nv, 3, 3), dtype=np.float64)
-    info = np.empty((2 * nu * nv, 3, 11), dtype=np.float64)
+    # (vertices are rounded to f32 BEFORE the gather — elementwise, so the result is the same bits as rounding the gathered f64
+    # arrays — and gathered by flat index: 8 M triangles in 10 s instead of 70)
+    Pf, vertf = P.astype(F32).reshape(-1, 3), vert.astype(F32).reshape(-1, 11)
+    pos = np.empty((2 * nu * nv, 3, 3), dtype=F32)
+    info = np.empty((2 * nu * nv, 3, 11), dtype=F32)
     for t, corners in enumerate(tri_idx):
         for k, c in enumerate(corners):
             ci, cj = quads[c]
-            pos[t::2, k] = P[ci, cj]
-            info[t::2, k] = vert[ci, cj]
-    return pos.astype(F32), info.reshape(-1, 33).astype(F32)
+            flat = ci * (nv + 1) + cj
+            pos[t::2, k] = Pf[flat]
+            info[t::2, k] = vertf[flat]
+    return pos, info.reshape(-1, 33)
 
 
 def box_mesh(lo, hi, div=1, uv_scale=1.0):
@@ -242,7 +248,7 @@ def _knot(U, scale=1.0):
 
 def dragon_proxy(num_triangles=80000, seed=0xD5A60, size=20.0):
     """Config 2: a displaced (2,3) torus-knot tube (2*nu*nv triangles) on a ground quad."""
-    nv = {80000: 20, 871414: 41}.get(num_triangles)
+    nv = {80000: 20, 871414: 41, 8000000: 128}.get(num_triangles)
     if nv is None:
         nv = 16
         while num_triangles % (2 * nv):
@@ -264,7 +270,19 @@ def dragon_proxy(num_triangles=80000, seed=0xD5A60, size=20.0):
         r = 0.45 + 0.35 * fbm3(q, seed, 3)
         return (c + radial * r[..., None]) * (size / 3.5)
 
-    pos, info = grid_surface(fn, nu, nv, (64.0, 2.0))
+    # OKRT_SCENE_CACHE=<dir>: the generated mesh is kept on disk (profiling runs start the same bench command five times; the
+    # 8 M-triangle mesh takes over a minute to generate)
+    cache = os.environ.get("OKRT_SCENE_CACHE")
+    files = [os.path.join(cache, f"dragon_{num_triangles}_{seed:x}_{size}_{k}.npy") for k in ("pos", "info")] if cache else []
+    if files and all(os.path.exists(f) for f in files):
+        pos, info = np.load(files[0]), np.load(files[1])
+    else:
+        pos, info = grid_surface(fn, nu, nv, (64.0, 2.0))
+        if files:
+            os.makedirs(cache, exist_ok=True)
+            for f, a in zip(files, (pos, info)):
+                np.save(f + ".tmp.npy", a)
+                os.replace(f + ".tmp.npy", f)
     s = SceneDescription(f"dragon-proxy-{num_triangles}")
     s.meshes.append((pos, info))
     lo = float(pos[..., 1].min())

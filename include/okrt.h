@@ -348,6 +348,10 @@ okrt_status okrt_get_fast_structure(okrt_ctx* ctx, void* nodes64, uint32_t node_
  *                   (the reference-order traversal over the uploaded tables; RaytracerCS.hlsl:218-334)
  *   CLOSEST_HIT_FAST o[3] d[3] numSpheres(bits) -> distance, hit?, nodes visited, hitIdx, triIdx
  *                   (the derived traversal structure, walked by one thread per ray)
+ *   CLOSEST_HIT_TRACE o[3] d[3] numSpheres(bits) -> distance, hit?, 0, hitIdx, triIdx
+ *                   (the same structure, but through traceKernel ITSELF — the persistent bounce-ray kernel with its queue shards,
+ *                   lane refill, step blocks and LDS stack: the rays are put on a sharded queue, one launch traces them and
+ *                   the hit records are read back; numSpheres is taken from the first record)
  * and, containing transcendentals (device libm vs host libm: last-ulp agreement only):
  *   RANDOM_VECTOR   seed                      -> v[3], new seed          (GPU-Utilities.hlsli:56-70)
  *   REFLECTANCE     cosine, index             -> value                   (RaytracerCS.hlsl:100-105)
@@ -365,7 +369,8 @@ typedef enum okrt_kat {
     OKRT_KAT_PCG_HASH = 0, OKRT_KAT_RANDOM_FLOAT = 1, OKRT_KAT_RAY_SPHERE = 2, OKRT_KAT_RAY_TRIANGLE = 3, OKRT_KAT_RAY_AABB = 4,
     OKRT_KAT_REFRACT = 5, OKRT_KAT_SAMPLE_TEXTURE = 6, OKRT_KAT_SAMPLE_ENV = 7, OKRT_KAT_CLOSEST_HIT = 8,
     OKRT_KAT_CLOSEST_HIT_FAST = 9, OKRT_KAT_RANDOM_VECTOR = 10, OKRT_KAT_REFLECTANCE = 11, OKRT_KAT_REFLECT_DIRECTION = 12,
-    OKRT_KAT_TRANSPARENCY_BOUNCE = 13, OKRT_KAT_PRIMARY_RAY = 14, OKRT_KAT_SEGMENT_RAY = 15, OKRT_KAT_IEEE_SHORTCUTS = 16
+    OKRT_KAT_TRANSPARENCY_BOUNCE = 13, OKRT_KAT_PRIMARY_RAY = 14, OKRT_KAT_SEGMENT_RAY = 15, OKRT_KAT_IEEE_SHORTCUTS = 16,
+    OKRT_KAT_CLOSEST_HIT_TRACE = 17
 } okrt_kat;
 okrt_status okrt_debug_kat(okrt_ctx* ctx, okrt_kat op, uint32_t n, const float* in, uint32_t in_floats, float* out, uint32_t out_floats);
 

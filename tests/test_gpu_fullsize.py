@@ -113,6 +113,37 @@ def test_config2_dragon_871k_720p_vs_oracle(oracle):
     rt.close()
 
 
+def test_dragon_8m_beyond_the_infinity_cache_vs_oracle(oracle):
+    """The one workload whose traversal structure (384 MB of Tri48 + 40 MB of Node4Q) does not fit the 256 MiB Infinity Cache
+    (bench.py --workload dragon8m: the roofline number that is HBM): same generator as config 2 at
+    8 000 000 triangles, 1280x720, fast path against the oracle on every 16th row and against the reference-order kernel up
+    to ties. The oracle gets the tables the host layer built for the GPU (a second exact-SAH build of 8 M triangles would
+    cost two more minutes); no environment map (the host layer keeps no copy of the cube faces to hand over)."""
+    desc = scenes.dragon_proxy(8000000)
+    desc.env_cross = None
+    W, H, K = 1280, 720, 16
+    rt, ga = gpu_frames(desc, W, H)
+    info = rt.ctx.build_info()
+    assert info["num_triangles"] == 8000002 and 64 * info["num_nodes"] + 48 * info["num_triangles"] > 256 << 20
+    octx = oracle.context()
+    for which in (abi.TABLE_TRI_POS, abi.TABLE_TRI_INFO, abi.TABLE_BVH, abi.TABLE_OCT, abi.TABLE_MESH):
+        octx.set_table(which, rt.table(which))
+    octx.resize(W, H)
+    oracle.lib.okrt_oracle_set_threads(octx.h, host_threads())
+    octx.set_tile(1, 0, K)
+    octx.render(rt.render_data)  # the frame the GPU just rendered (numAccumulationFrames = 1)
+    ca = octx.read_accum()
+    octx.close()
+    assert_rows_match(ga, ca, K)
+    rt.ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_REFERENCE)
+    rt.resetAccumulation()
+    rt.render()
+    ref = rt.ctx.read_accum()
+    frac_same, drops = assert_differences_are_ties(rt, ga, ref, 1)
+    assert frac_same >= 0.999 and drops <= 16, (frac_same, drops)
+    rt.close()
+
+
 # ---- config 3: glass + revolver-proxy + IBL, 1920x1080, NUM_BOUNCES = 1 (HEAD) and 8 (Q23) -------------------------
 @pytest.mark.parametrize("max_bounces", [1, 8])
 def test_config3_glass_1080p_vs_oracle(oracle, max_bounces):

@@ -301,3 +301,69 @@ def test_short_reciprocal_and_square_root_are_the_ieee_ones_for_every_float(gpu)
     bad_rcp, bad_sqrt = int(out[:, 0].sum()), int(out[:, 1].sum())
     where = out[(out[:, 0] > 0) | (out[:, 1] > 0)][:4]
     assert bad_rcp == 0 and bad_sqrt == 0, (bad_rcp, bad_sqrt, [[hex(int(v)) for v in row] for row in where])
+
+
+def test_the_bounce_kernel_itself_ray_by_ray():
+    """OKRT_KAT_CLOSEST_HIT_TRACE puts the probe's rays on a sharded queue and traces them with traceKernel — the persistent bounce-ray
+    kernel with its lane refill, shard stealing, step blocks, LDS stack and spill slab — where CLOSEST_HIT_FAST walks the same
+    structure with one thread and a private stack. Same closest-hit distance and hit flag for every ray, bit for bit (the
+    triangle carrying it may differ on equal-distance ties); ray counts that are no multiple of anything; and the sphere table."""
+    rng = np.random.default_rng(12)
+    for desc, n in ((scenes.small_mesh_scene(seed=5, n_objects=7, detail=12, with_textures=False), 70001),
+                    (scenes.dragon_proxy(80000), 200003),
+                    (scenes.test_scene_spheres(), 999)):
+        rt, sc, res = scenes.instantiate(desc, 64, 36)
+        rt.calculateProjectionData(); rt.updateBuffers()
+        o = rng.normal(0, 14, (n, 3)).astype(np.float32)
+        target = rng.normal(0, 5, (n, 3)).astype(np.float32)
+        d = target - o
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        rec = np.concatenate([o, d, np.full((n, 1), rt.render_data.numSpheres, np.uint32).view(np.float32)], 1)
+        fast = rt.ctx.kat(abi.KAT_CLOSEST_HIT_FAST, rec, 5).view(np.uint32)
+        trace = rt.ctx.kat(abi.KAT_CLOSEST_HIT_TRACE, rec, 5).view(np.uint32)
+        assert np.array_equal(trace[:, 0], fast[:, 0]) and np.array_equal(trace[:, 1], fast[:, 1]), desc.name
+        hit = fast[:, 1] == 1
+        assert hit.sum() > n // 20
+        assert (trace[hit, 3] == fast[hit, 3]).mean() > 0.999 and (trace[hit, 4] == fast[hit, 4]).mean() > 0.995
+        rt.close()
+
+
+def test_an_empty_child_slot_that_collapses_under_rounding_does_not_end_the_ray():
+    """A Node4Q's unused child slots carry an inverted box (lower plane 255, upper plane 0) that no ray enters — except when
+    255 * step / d is below half an ulp of the plane distance on all three axes AND the three distances are equal: a tiny node
+    seen from far away by a ray through its grid origin. Then tnear == tfar and the slot IS entered; its reference is
+    kEmptyRef, which the bounce kernel also uses for "no more work", so round 3's kernel dropped the rest of the ray's stack
+    there. Built here: a cluster a few float spacings wide at (30, 30, 30), seen from 8 000 units away (255 grid steps of its node
+    are far below half an ulp of that distance), behind which a large wall must still be hit."""
+    cluster = (np.array([30.0, 30.0, 30.0]) + np.random.default_rng(2).uniform(0, 6e-6, (30, 3, 3))).astype(np.float32)
+    wall = np.array([[[2000, -3000, -3000], [2000, 6000, -3000], [2000, -3000, 6000]], [[2000, 6000, 6000], [2000, -3000, 6000], [2000, 6000, -3000]]], np.float32)
+    desc = scenes.SceneDescription("collapse")
+    desc.meshes = [(np.concatenate([cluster, wall]), np.zeros((32, 33), np.float32))]
+    desc.entities = [scenes.MeshEntity(0, {})]
+    rt, sc, res = scenes.instantiate(desc, 16, 16)
+    rt.ctx.commit()
+    nodes, tris = rt.ctx.fast_structure()
+    exps = nodes[:, 3]
+    extent = 255.0 * np.ldexp(1.0, (exps & 255).astype(np.int64) - 127)
+    small = [k for k in range(len(nodes)) if extent[k] < 1e-2 and (nodes[k, 4:8] == 0xFFFFFFFF).any() and (nodes[k, 4:8] != 0xFFFFFFFF).any()]
+    assert small, "the builder made no small node with an unused slot"
+    recs = []
+    dn = np.float32(1.0) / np.sqrt(np.float32(3.0))  # the kernel normalises (1, 1, 1): three equal components
+    iq = np.float32(1.0) / dn
+    for k in small:
+        O = nodes[k, 0:3].view(np.float32)
+        steps = np.ldexp(np.float32(1.0), ((exps[k] >> np.array([0, 8, 16])) & 255).astype(np.int64) - 127).astype(np.float32)
+        for L in (8192.0, 16384.0, 24576.0, 32768.0, 49152.0, 65536.0):
+            ro = (O - np.float32(L)).astype(np.float32)
+            D = (O - ro).astype(np.float32)
+            B = (D * iq).astype(np.float32)
+            absorbed = all(np.float32(255.0 * float(steps[a] * iq) + float(B[a])) == B[a] for a in range(3))  # fma(255, A, B) == B
+            if D[0] == D[1] == D[2] and absorbed:  # every plane of every child slot, the empty ones too, is at the same distance
+                recs.append(np.concatenate([ro, np.float32([1, 1, 1]), np.zeros(1, np.float32)]))
+    assert recs, "no ray through a grid origin with three equal, absorbing plane distances"
+    rec = np.array(recs, np.float32)
+    fast = rt.ctx.kat(abi.KAT_CLOSEST_HIT_FAST, rec, 5).view(np.uint32)
+    trace = rt.ctx.kat(abi.KAT_CLOSEST_HIT_TRACE, rec, 5).view(np.uint32)
+    assert (fast[:, 1] == 1).all()  # every such ray hits the cluster or, past it, the wall
+    assert np.array_equal(trace[:, 0], fast[:, 0]) and np.array_equal(trace[:, 1], fast[:, 1]), (trace[:, :2], fast[:, :2])
+    rt.close()

@@ -70,7 +70,7 @@ def main():
     env = dict(os.environ, TMPDIR="/tmp")
     tag = f"{args.workload}_f{args.frames}"
     cmd = ["python3", os.path.join(REPO, "bench.py"), "--workload", args.workload, "--steps", str(args.frames), "--warmup", str(args.frames),
-           "--frames-per-launch", str(args.frames), "--no-cpu-baseline", "--no-single-call"]
+           "--frames-per-launch", str(args.frames), "--no-cpu-baseline", "--no-single-call", "--no-repeats"]
     bench_lines = {}
     for name, flags in PASSES:
         if name not in args.passes.split(","):
