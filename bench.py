@@ -403,11 +403,13 @@ def main():
             return
         group.gather()
 
-    def sync():
+    def sync(before_region=False):
         for st in ranks:
             st.ctx.synchronize()
         if store:
-            store.tight_barrier()  # the ranks leave it within microseconds of each other: it brackets the timed region
+            # leaves all ranks within microseconds of each other and adds microseconds itself (the file-polling barrier: up to 2 ms,
+            # the length of an 8-GPU 20-frame region); in front of a region the ranks first collect asleep
+            store.tight_barrier(gather_first=before_region)
 
     # ---- roofline numerator: the reference-order counters of one frame of this workload -------
     def counted(st, traversal, max_bounces):
@@ -492,7 +494,7 @@ def main():
         st.ctx.reset_counters()
     ctx.set_option(abi.OPT_TIMING, min(5 * args.steps, 4096))  # HIP events around every kernel of every launch set, on the stream they run on (ring: all five regions)
     enqueue_s[0], enqueue_s[1] = 0.0, 0
-    sync()
+    sync(before_region=True)
     t0 = time.perf_counter()
     ctx.timer_begin()
     run_frames(steps_here, not samples_split)
@@ -512,7 +514,7 @@ def main():
     repeats_done = 0
     if not samples_split and not args.no_repeats:
         for _ in range(4):
-            sync()
+            sync(before_region=True)
             t1 = time.perf_counter()
             run_frames(steps_here, True)
             exchange(final=True)

@@ -121,11 +121,12 @@ class FileStore:
     def barrier(self):
         self.allgather(b"")
 
-    def tight_barrier(self):
-        """A barrier the ranks LEAVE within microseconds of each other: what brackets a timed region (a file-polling barrier lets
-        its early arrivals sleep up to 2 ms between looks, which is the length of an 8-GPU, 20-frame region). Every rank bumps its
-        own 8-byte counter in a shared memory-mapped file (one 64-byte line per rank) and spins until every counter has reached
-        the round; the ordinary barrier in front of it collects the ranks first, so the spin is short."""
+    def tight_barrier(self, gather_first=False):
+        """A barrier the ranks LEAVE within microseconds of each other and that costs microseconds once the last rank has arrived:
+        what brackets a timed region (the file-polling barrier lets its early arrivals sleep up to 2 ms between looks, which is
+        the length of an 8-GPU, 20-frame region). Every rank bumps its own 8-byte counter in a shared memory-mapped file (one
+        64-byte line per rank) and SPINS until every counter has reached the round. gather_first = True puts the ordinary
+        barrier in front, so that ranks which may be seconds apart (scene set-up) do their waiting asleep."""
         import mmap
         import struct
         if getattr(self, "_bar", None) is None:
@@ -138,7 +139,8 @@ class FileStore:
             finally:
                 os.close(fd)
             self._bar_round = 0
-        self.barrier()
+        if gather_first:
+            self.barrier()
         self._bar_round += 1
         struct.pack_into("<Q", self._bar, 64 * self.rank, self._bar_round)
         deadline = time.monotonic() + self.timeout

@@ -172,6 +172,9 @@ typedef enum okrt_option {
      * (Sponza-class), 1.88 -> 0.67 (871 k-triangle mesh); sets of 4: 0.64 -> 0.59, 0.66 -> 0.33; sets of 16:
      * 0.52 -> 0.57, 0.32 -> 0.29 — large persistent grids sharing the GPU cost each other more than the overlap returns
      * unless the tail is long, hence the default of 4; a host with a tail-heavy scene sets 32.
+     * Small tiles (round 4): a LARGER launch set that traces at most 12 Mi camera rays — one rank's stripes of an N-way split —
+     * is issued as two sub-sets that ride the slots the same way (8-way split of a 1080p frame, 20 frames: 1.67 -> 1.58 ms per
+     * rank; a full 1080p frame, where it would cost 4.5 %, is not cut). Same framebuffers bit for bit.
      * Footprint: the queues of up to FOUR launch sets of up to n frames (default: 4 x 0.76 GB at 1080p). 0 = one launch
      * set at a time. */
     OKRT_OPT_PIPELINE = 8

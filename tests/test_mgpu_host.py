@@ -67,7 +67,7 @@ def _store_rank(rank, world, key, root, out):
     for k in range(5):
         time.sleep(0.003 * ((rank + k) % world))  # staggered arrivals
         arrive = time.monotonic()  # (CLOCK_MONOTONIC: one clock for every process of the machine)
-        st.tight_barrier()
+        st.tight_barrier(gather_first=(k % 2 == 0))  # with and without the sleeping barrier in front
         stamps.append((arrive, time.monotonic()))
     st.close()
     out.put((rank, [len(g) for g in got], [g[:1] for g in got], len(blob), total,
