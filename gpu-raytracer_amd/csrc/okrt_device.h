@@ -487,14 +487,28 @@ OKRT_DEV Ray primaryRay(const okrt_render_data& rd, uint32_t frameN, uint32_t px
     Ray ray;
     ray.origin = ld3(rd.cameraPosition);
     ray.direction = matDir(rd.cameraInverseViewMatrix, tdir);
-    // applyDOF :208-216 (always runs: 2 draws)
-    float angle = randomFloat(seed) * 2.f * kPi;
-    float cx = cosf(angle), cy = sinf(angle);
-    float r = sqrtf(randomFloat(seed));
-    float jx = (cx * r) * rd.dofStrength, jy = (cy * r) * rd.dofStrength;
-    V3 rayOffset = fma3(ld3(rd.cameraUpDir), jy, ld3(rd.cameraRightDir) * jx);
+    // applyDOF :208-216 (always runs: 2 draws). With strength 0 the lens offset is (+-0, +-0, +-0) — cos, sin and sqrt are finite, the
+    // basis vectors finite — and origin + (+-0) is the origin itself for every component but a NEGATIVE zero (-0 + +0 = +0): then the
+    // two draws are consumed and the trigonometry, whose only use is the sign of those zeros, is not evaluated (same bits; 2-7 % of
+    // the camera kernel).
     V3 focusPoint = fma3(ray.direction, rd.dofDistance + rd.cameraNearZ, ray.origin);
-    ray.origin = ray.origin + rayOffset;
+    const float* cu = rd.cameraUpDir;
+    const float* cr = rd.cameraRightDir;
+    const bool noLens = rd.dofStrength == 0.f && __float_as_uint(ray.origin.x) != 0x80000000u && __float_as_uint(ray.origin.y) != 0x80000000u &&
+                        __float_as_uint(ray.origin.z) != 0x80000000u &&
+                        fabsf(cu[0]) <= kFltMax && fabsf(cu[1]) <= kFltMax && fabsf(cu[2]) <= kFltMax &&
+                        fabsf(cr[0]) <= kFltMax && fabsf(cr[1]) <= kFltMax && fabsf(cr[2]) <= kFltMax;  // (NaN fails every comparison)
+    if (noLens) {
+        (void)pcgHash(seed);
+        (void)pcgHash(seed);
+    } else {
+        float angle = randomFloat(seed) * 2.f * kPi;
+        float cx = cosf(angle), cy = sinf(angle);
+        float r = sqrtf(randomFloat(seed));
+        float jx = (cx * r) * rd.dofStrength, jy = (cy * r) * rd.dofStrength;
+        V3 rayOffset = fma3(ld3(rd.cameraUpDir), jy, ld3(rd.cameraRightDir) * jx);
+        ray.origin = ray.origin + rayOffset;
+    }
     ray.direction = normalize(focusPoint - ray.origin);
     return ray;
 }

@@ -19,7 +19,7 @@ struct LaunchPlanParams {
 
 // A launch set of n frames is issued in one piece (1) or as that many equal sub-sets that ride the pipeline slots. Sub-sets
 // pay for themselves where a set's fixed cost — the last dependent chains of each kernel on an emptied GPU, ~0.35 ms on the
-// Sponza-class scene — is a large share of its time: one rank's stripes of an 8-way split, 20 frames: 1.67 -> 1.5x ms;
+// Sponza-class scene — is a large share of its time: one rank's stripes of an 8-way split, 20 frames: 1.67 -> 1.58 ms;
 // on a full 1080p frame the two persistent grids cost each other more than the overlap returns (+4.5 %).
 inline uint32_t launchSubSets(const LaunchPlanParams& p, uint32_t n) {
     if (!p.pipelineOn || !p.batchable || p.splitParts < 2) return 1;

@@ -288,6 +288,45 @@ def test_primary_ray(gpu, oracle, lib):
     ort.close()
 
 
+@pytest.mark.parametrize("case", ["plain", "plus_zero", "minus_zero", "nan_basis"])
+def test_primary_ray_without_a_lens_keeps_the_oracles_bits(gpu, oracle, lib, case):
+    """Depth of field off (the reference's default): the device skips the lens trigonometry, whose product with strength 0 is a
+    signed zero that cannot change an origin component unless that component is -0 (okrt_device.h: primaryRay). The origin must be
+    the oracle's BIT FOR BIT — the oracle always evaluates the lens — with the same RNG state after the two always-consumed draws:
+    an ordinary position, a +0 component (unchanged by either zero), a -0 component (the device takes the full path: -0 + +0 = +0),
+    a NaN in the camera basis (full path: the NaN reaches the origin)."""
+    desc = scenes.small_mesh_scene(seed=3)
+    ort, _, _ = oracle.instantiate(desc, 640, 360)
+    ort.setDOF(0.0, 9.0)
+    ort.updateBuffers()
+    rd = type(ort.render_data).from_buffer_copy(bytes(ort.render_data))
+    if case == "plus_zero":
+        rd.cameraPosition[1] = 0.0
+    elif case == "minus_zero":
+        rd.cameraPosition[1] = -0.0
+        rd.cameraPosition[2] = -0.0
+    elif case == "nan_basis":
+        rd.cameraUpDir[0] = float("nan")
+    lib.okrt_oracle_kat_primary_ray.argtypes = [C.POINTER(type(rd)), C.c_uint32, C.c_uint32, F3, F3, C.POINTER(C.c_uint32)]
+    rdf = np.frombuffer(bytes(rd), np.float32)
+    rng = np.random.default_rng(11)
+    n = 1500
+    px, py = rng.integers(0, 640, n).astype(np.uint32), rng.integers(0, 360, n).astype(np.uint32)
+    rec = np.concatenate([bits(px)[:, None], bits(py)[:, None], np.broadcast_to(rdf, (n, 60))], 1)
+    got = gpu.kat(abi.KAT_PRIMARY_RAY, rec, 7)
+    want_o = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        o, d, s = F3(), F3(), C.c_uint32(0)
+        lib.okrt_oracle_kat_primary_ray(C.byref(rd), int(px[i]), int(py[i]), o, d, C.byref(s))
+        want_o[i] = list(o)
+        assert s.value == got[i, 6:].view(np.uint32)[0], i
+        assert close(got[i, 3:6], list(d), 1e-5, 1e-5).all(), i
+    assert np.array_equal(got[:, :3].view(np.uint32), want_o.view(np.uint32)), case  # origins bit for bit, signs of zeros and NaNs included
+    if case == "minus_zero":
+        assert (want_o[:, 1].view(np.uint32) == 0).any() and (want_o[:, 1].view(np.uint32) == 0x80000000).any()  # both signs really occur
+    ort.close()
+
+
 def test_short_reciprocal_and_square_root_are_the_ieee_ones_for_every_float(gpu):
     """okrt_device.h computes 1/x and sqrt(x) in the traversal with the hardware estimate plus the last correction step of the
     compiler's IEEE sequence (3 and 9 instructions instead of 10 and 16) wherever the exponent is mid-range. All 2^32 bit
