@@ -183,7 +183,7 @@ def cpu_baseline(desc, width, height, frame_index_rd, target_seconds=15.0):
 
 
 def roofline_report(args, world, samples_split, interval_ms, launches, frames, build, ref_c, fast_c, cam_c, ref_trav_bytes,
-                    ref_shade_bytes, trace_ms_frame, shade_ms_frame, other_ms_frame):
+                    ref_shade_bytes, trace_ms_frame, shade_ms_frame, other_ms_frame, terminal=False):
     """The roofline object of the JSON line (DESIGN.md §4 "Roofline accounting").
 
     Per kernel of the fast pipeline, live: average launch duration from the HIP events the library records around every
@@ -229,7 +229,10 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
     if args.traversal == "fast" and len(interval_ms) >= 2:
         # camera-segment kernel: generates, traces (wave-uniform node / triangle loads: once per WAVE), shades, appends queue 1
         cam_surv = bounce_rays if mb == 1 else (cam_hits if mb > 1 else 0)  # (mb > 1: every camera hit continues)
-        cam_alg = 56 * cam_surv + slot * max(pixels - cam_surv, 0) + 64 * cam_hits + 16 * cam_taps + 16 * cam_env
+        # (terminal: the survivors' next segment is the last and a hit there adds nothing — the camera kernel also writes the 16-byte
+        # radiance slot such a hit ends with, okrt_fast_trace.hip: FusedArgs::terminalNext)
+        term1 = terminal and mb == 1
+        cam_alg = (56 + (16 if term1 else 0)) * cam_surv + slot * max(pixels - cam_surv, 0) + 64 * cam_hits + 16 * cam_taps + 16 * cam_env
         cam_l2 = (64 * cam_nodes + 48 * cam_tris) / 64 + cam_alg
         add("tracePacketKernel<FUSED> (camera segment: generate + packet traversal + shade + append)", interval_ms[0] + interval_ms[1], cam_alg, cam_l2,
             structure_bytes, 0)
@@ -237,6 +240,19 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
             tr = sum(interval_ms[2::2])
             sh = sum(interval_ms[3::2])
             # traceKernel: 32 B ray read + 20 B hit record write per ray; per-lane gathers of 64 B per node visit, 48 B per triangle test
+            # (terminal, NUM_BOUNCES = 1: MODE 1 writes 4 bytes per MISS and nothing per hit; missKernel reads a 4-byte word per ray,
+            # 48 B of queue entry + a 16-byte tap + a 16-byte slot per miss. With more bounces only the last segment is reduced and the
+            # per-segment ray counts are not known here: the full-record sizes are kept, an over-estimate, and said so.)
+            if term1:
+                add("traceKernel<MODE 1> (bounce-ray traversal, closest hit; hit-or-miss record)", tr, 32 * bounce_rays + 4 * later_env,
+                    64 * b_nodes + 48 * b_tris + 32 * bounce_rays, structure_bytes * mb, 32 * bounce_rays)
+                ms_alg = 4 * bounce_rays + (48 + 16 + 16) * later_env
+                ms_stream = 4 * bounce_rays
+                if frames_per_launch > 1:
+                    ms_alg += (16 * frames_per_launch + 36) * pixels / frames_per_launch
+                    ms_stream += (16 * frames_per_launch + 16) * pixels / frames_per_launch
+                add("missKernel + accumulateKernel (last segment's misses: environment lookup; frame-slot accumulation)", sh, ms_alg, ms_alg, 0, ms_stream)
+                tr = sh = 0
             add("traceKernel (bounce-ray traversal)", tr, 52 * bounce_rays, 64 * b_nodes + 48 * b_tris + 52 * bounce_rays, structure_bytes * mb, 32 * bounce_rays)
             later_surv = max(bounce_rays - cam_surv, 0)  # rays of segments 2..: appended by the later shading kernels
             sh_alg = (56 + 20) * bounce_rays + 64 * later_hits + 16 * later_taps + 16 * later_env + slot * max(bounce_rays - later_surv, 0) + 56 * later_surv
@@ -338,6 +354,10 @@ def main():
     ap.add_argument("--no-repeats", action="store_true", help="skip the four untimed-for-the-headline repeats of the K-step region (profiling runs)")
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
     ap.add_argument("--max-bounces", type=int, default=1, help="NUM_BOUNCES (RaytracerCS.hlsl:6; HEAD = 1, used for every graded number)")
+    ap.add_argument("--last-segment", default="shortcut", choices=["shortcut", "full", "any-hit"],
+                    help="what the fast pipeline does on the last path segment where a hit there provably adds +-0 (no emitters, no lights): "
+                         "'shortcut' (default, OKRT_OPT_LAST_SEGMENT_SHORTCUT = 1: hit-or-miss record, only misses shaded; bit-identical), "
+                         "'full' (every segment shaded in full), 'any-hit' (developer knob: OKRT_OPT_LAST_SEGMENT_ANY_HIT, not closest-hit rays)")
     ap.add_argument("--split", default="tiles", choices=["tiles", "samples"],
                     help="N > 1: 'tiles' = image-space stripes + gather (the north-star path); 'samples' = every rank renders "
                          "the whole frame for its own block of frame indices, accumulations are summed with one reduce")
@@ -387,6 +407,8 @@ def main():
     for st in ranks:
         st.ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_FAST if args.traversal == "fast" else abi.TRAVERSAL_REFERENCE)
         st.ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
+        st.ctx.set_option(abi.OPT_LAST_SEGMENT_SHORTCUT, 0 if args.last_segment == "full" else 1)
+        st.ctx.set_option(abi.OPT_LAST_SEGMENT_ANY_HIT, 1 if args.last_segment == "any-hit" else 0)
         if world > 1 and not samples_split:
             st.ctx.set_tile(STRIPE_ROWS, st.rank, world)
     if world == 1 and os.environ.get("OKRT_BENCH_TILE"):  # developer knob: time one rank's share of an N-way split on 1 GPU
@@ -523,6 +545,30 @@ def main():
             repeats_done += 1
         interval_ms, interval_launches, interval_frames = ctx.interval_ms()  # all five regions' launch sets (same shapes)
     ctx.set_option(abi.OPT_TIMING, 0)
+    # Does the last-segment shortcut apply to this workload? (okrt.h: OKRT_OPT_LAST_SEGMENT_SHORTCUT — materials without emission and
+    # with |albedo| <= 1, no light in the frame's RenderData.) If it does, the same K-step region is also timed with every segment
+    # shaded in full and with any-hit on the last segment, under their own names; the graded line stays the closest-hit default.
+    rd_now = rt.render_data
+    shortcut_applies = (args.traversal == "fast" and args.max_bounces >= 1 and bool(build["flags"] & abi.BUILD_FLAG_DARK_MATERIALS)
+                        and rd_now.numDirLights == 0 and rd_now.numPointLights == 0 and rd_now.numSpotLights == 0)
+    terminal = shortcut_applies and args.last_segment != "full"
+    alt_ms = {}
+    if world == 1 and shortcut_applies and not args.no_single_call:
+        for name, (opt_short, opt_any) in (("full_shading", (0, 0)), ("any_hit", (1, 1))):
+            ctx.set_option(abi.OPT_LAST_SEGMENT_SHORTCUT, opt_short)
+            ctx.set_option(abi.OPT_LAST_SEGMENT_ANY_HIT, opt_any)
+            run_frames(shape_warm, False)
+            best = None
+            for _ in range(3):
+                sync(before_region=True)
+                t1 = time.perf_counter()
+                run_frames(steps_here, True)
+                sync()
+                ms = (time.perf_counter() - t1) * 1e3 / args.steps
+                best = ms if best is None else min(best, ms)
+            alt_ms[name] = best
+        ctx.set_option(abi.OPT_LAST_SEGMENT_SHORTCUT, 0 if args.last_segment == "full" else 1)
+        ctx.set_option(abi.OPT_LAST_SEGMENT_ANY_HIT, 1 if args.last_segment == "any-hit" else 0)
     if args.traversal == "reference":  # the reference-order kernel only counts with OKRT_OPT_COUNTERS (slow): segments of the counted frame x frames
         rays_local = ref_counters["segments"] * steps_here
     gpu_event_ms = ctx.timer_elapsed_ms()
@@ -544,7 +590,7 @@ def main():
 
     # for reference: the same frames issued one okrt_render call per frame (the reference's main-loop shape), and the
     # configuration BASELINE.json names as such: 1024 spp of progressive accumulation, end to end
-    single_ms = single_sync_ms = spp1024_ms = readback_ms = None
+    single_ms = single_sync_ms = spp1024_ms = readback_ms = single_frame_ms = None
     if world == 1 and not args.no_single_call:
         def per_call(defer):
             ctx.set_option(abi.OPT_DEFER, defer)
@@ -554,6 +600,18 @@ def main():
                 rt.render()
             ctx.synchronize()
             return (time.perf_counter() - t1) * 1e3 / 64
+        # SURVEY 8d "ms/frame for ONE 1-spp frame": one frame launched and waited for, nothing deferred, nothing else in flight
+        ctx.set_option(abi.OPT_DEFER, 0)
+        ctx.set_option(abi.OPT_PIPELINE, 0)
+        lat = []
+        for _ in range(17):
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            rt.render()
+            ctx.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        single_frame_ms = sorted(lat[1:])[8]  # median of 16 (the first pays the single-frame queue shape)
+        ctx.set_option(abi.OPT_PIPELINE, 4)
         single_sync_ms = per_call(0)   # every okrt_render launches its own frame
         single_ms = per_call(16)       # the default: the library defers and batches the accumulation loop's frames
         rt.resetAccumulation()
@@ -616,6 +674,13 @@ def main():
                        # the graded K-step region (first value = ms_per_step) and the same region repeated four more times
                        "ms_per_step_repeats": [round(v, 4) for v in repeat_ms],
                        "ms_per_step_repeats_spread": round((max(repeat_ms) - min(repeat_ms)) / min(repeat_ms), 4),
+                       "last_segment": ("any-hit on the last segment (OKRT_OPT_LAST_SEGMENT_ANY_HIT): NOT closest-hit rays, developer knob, not a graded number" if terminal and args.last_segment == "any-hit" else
+                                        "closest-hit traversal, hit-or-miss record, only misses shaded: no emitters and no lights in this scene, so a last-segment hit adds +-0 "
+                                        "(OKRT_OPT_LAST_SEGMENT_SHORTCUT, default, framebuffers bit-identical to full shading)" if terminal else
+                                        "shaded in full" + ("" if not shortcut_applies else " (--last-segment full)")),
+                       "ms_per_step_last_segment_full_shading": round(alt_ms["full_shading"], 4) if "full_shading" in alt_ms else None,
+                       "ms_per_step_last_segment_any_hit": round(alt_ms["any_hit"], 4) if "any_hit" in alt_ms else None,
+                       "ms_single_frame": round(single_frame_ms, 4) if single_frame_ms else None,
                        "ms_per_step_one_call_per_frame": round(single_ms, 4) if single_ms else None,
                        "ms_per_step_one_call_per_frame_defer_off": round(single_sync_ms, 4) if single_sync_ms else None,
                        "ms_per_step_1024spp": round(spp1024_ms, 4) if spp1024_ms else None,
@@ -636,7 +701,7 @@ def main():
                                      "nothing about scaling — it exercises the N-rank code path")
         out["roofline"] = roofline_report(args, world, samples_split, interval_ms, interval_launches, interval_frames, build,
                                           ref_counters, fast_counters, camera_counters, ref_trav_bytes, ref_shade_bytes, trace_ms_frame,
-                                          shade_ms / frames, other_ms / frames)
+                                          shade_ms / frames, other_ms / frames, terminal)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, W, H, None)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -46,6 +46,10 @@ struct okrt_ctx {
     bool countersOn = false, timingOn = false;
     int traversal = OKRT_TRAVERSAL_FAST;
     int maxBounces = 1;
+    // SceneView::lastSegmentDark = lastSegmentShortcut && materialsDark && no light in the frame's RenderData && counters off
+    bool materialsDark = true;          // every Material in t6 / t7: emission colour * power == (+-0)^3 and |albedo| <= 1 (recomputed at upload)
+    bool lastSegmentShortcut = true;    // OKRT_OPT_LAST_SEGMENT_SHORTCUT
+    bool lastSegmentAnyHit = false;     // OKRT_OPT_LAST_SEGMENT_ANY_HIT
     bool tablesDirty = true;   // re-validate before the next render
     bool tablesValid = false;
     FastScene* fast = nullptr;  // derived structure (okrt_fast.h); rebuilt when geometry changes
@@ -292,7 +296,29 @@ uint32_t instanceFlags(const okrt_ctx* c) {
     return flags;
 }
 
-SceneView makeView(const okrt_ctx* c) {
+// Is a hit on the last path segment worth nothing in this scene? (SceneView::lastSegmentDark has the argument.) Per material:
+// the product the shader forms, emission colour * power (RaytracerCS.hlsl:152), is exactly zero in every component (NaN and
+// inf * 0 fail the comparison), and |albedo| <= 1 so that the path throughput — a product of lerp(albedo, 1, metallicFactor)
+// factors starting at 1 (:505) — can never leave [-1, 1]: 0 * throughput stays a signed zero. Sampled albedo lies in [0, 1].
+bool materialIsDark(const Material& m) {
+    for (int k = 0; k < 3; ++k) {
+        const float e = m.emission[k] * m.emissionPower;
+        if (!(e == 0.f) || !(std::fabs(m.albedo[k]) <= 1.f)) return false;
+    }
+    return true;
+}
+bool allMaterialsDark(const okrt_ctx* c) {
+    const Table& sp = c->tables[OKRT_TABLE_SPHERE];
+    const Table& me = c->tables[OKRT_TABLE_MESH];
+    for (uint32_t i = 0; i < sp.count; ++i)
+        if (!materialIsDark(((const SphereRec*)sp.host.data())[i].material)) return false;
+    for (uint32_t i = 0; i < me.count; ++i)
+        if (!materialIsDark(((const MeshRec*)me.host.data())[i].material)) return false;
+    return true;
+}
+bool frameHasNoLights(const okrt_render_data& rd) { return (rd.numPointLights | rd.numSpotLights | rd.numDirLights) == 0u; }
+
+SceneView makeView(const okrt_ctx* c, const okrt_render_data* rd = nullptr) {
     SceneView s{};
     s.triPos = (const TriangleRec*)c->tables[OKRT_TABLE_TRI_POS].dev.ptr;
     s.triInfo = (const TriangleInfoRec*)c->tables[OKRT_TABLE_TRI_INFO].dev.ptr;
@@ -312,6 +338,9 @@ SceneView makeView(const okrt_ctx* c) {
     s.texH = c->texH;
     s.envFace = c->envFace;
     s.maxBounces = (uint32_t)c->maxBounces;
+    // (with OKRT_OPT_COUNTERS every segment is shaded in full: tex_taps / mesh_hits count the reference's work)
+    s.lastSegmentDark = (rd && c->lastSegmentShortcut && c->materialsDark && !c->countersOn && frameHasNoLights(*rd)) ? 1u : 0u;
+    s.lastSegmentAnyHit = (s.lastSegmentDark && c->lastSegmentAnyHit) ? 1u : 0u;
     return s;
 }
 
@@ -454,6 +483,7 @@ okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint3
             OKRT_HIP(c, hipStreamSynchronize(c->stream));  // `packed` dies at return
         }
     }
+    if (slot == OKRT_TABLE_SPHERE || slot == OKRT_TABLE_MESH) c->materialsDark = allMaterialsDark(c);
     if (slot == OKRT_TABLE_TRI_POS || slot == OKRT_TABLE_TRI_INFO || slot == OKRT_TABLE_BVH || slot == OKRT_TABLE_OCT || slot == OKRT_TABLE_MESH) {
         c->tablesDirty = true;
         c->fastDirty = true;
@@ -722,7 +752,7 @@ okrt_status okrt_get_build_info(okrt_ctx* c, okrt_build_info* out) {
     out->max_depth = bi.maxDepth;
     out->device_ms = bi.deviceMs;
     out->wall_ms = bi.wallMs;
-    out->flags = instanceFlags(c);
+    out->flags = instanceFlags(c) | (c->materialsDark ? OKRT_BUILD_FLAG_DARK_MATERIALS : 0u);
     c->buildFlagsRead = true;
     return OKRT_OK;
 }
@@ -746,7 +776,7 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
     if (vs != OKRT_OK) return vs;
     if (!c->tile.rows) return OKRT_OK;
 
-    SceneView view = makeView(c);
+    SceneView view = makeView(c, rd);
     unsigned long long* counters = c->countersOn ? (unsigned long long*)c->counters.ptr : nullptr;
     const bool referenceOrder = c->traversal == OKRT_TRAVERSAL_REFERENCE || rd->debugMode != 0;
     if (!referenceOrder) {
@@ -971,6 +1001,8 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
             c->pipelineOn = value != 0 && c->side[1] != nullptr;
             if (value) c->pipelineMaxFrames = (uint32_t)value;
             return OKRT_OK;
+        case OKRT_OPT_LAST_SEGMENT_SHORTCUT: c->lastSegmentShortcut = value != 0; return OKRT_OK;
+        case OKRT_OPT_LAST_SEGMENT_ANY_HIT: c->lastSegmentAnyHit = value != 0; return OKRT_OK;
         case OKRT_OPT_DEBUG_FAIL_ALLOC:
             if (value < 0 || value > 1000) return fail(c, OKRT_ERR_INVALID_ARG, "debug fail alloc: 0..1000");
             fastDebugFailAlloc((int)value);

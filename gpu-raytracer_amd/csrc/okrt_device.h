@@ -72,6 +72,12 @@ struct SceneView {
     const SpotLightRec* spotLights;     // t10
     uint32_t numOct, numTextures, texW, texH, envFace;
     uint32_t maxBounces;
+    // 1 = a HIT on the last path segment adds nothing (okrt_context.hip: lastSegmentDark): no light of any kind in this frame's
+    // RenderData, every material's emission colour * power is a zero vector and every albedo lies in [-1, 1]. Then the shader's
+    // `light += emission * contribution * (1 - transparencyFactor)` (RaytracerCS.hlsl:509-510) is light + (+-0): the path ends
+    // with the radiance it carried, which is +0 (emission and lights are the only sources before a miss, :448-493).
+    uint32_t lastSegmentDark;
+    uint32_t lastSegmentAnyHit;  // OKRT_OPT_LAST_SEGMENT_ANY_HIT (only with lastSegmentDark): the last segment's ray ends at its first accepted hit
 };
 
 // Per-thread counters; summed into okrt_counters when OKRT_OPT_COUNTERS is on.

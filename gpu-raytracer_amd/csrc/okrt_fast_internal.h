@@ -115,6 +115,9 @@ struct FastView {
 // miss, BSDF sample. Updates ray / throughput / radiance / RNG state in place; returns true when the path continues.
 OKRT_DEV bool shadeSegment(const SceneView& s, const okrt_render_data& rd, Ray& ray, const Hit& h, uint32_t bounce, uint32_t lastBounce,
                            V3& contribution, V3& light, uint32_t& seed, PathCounters& cnt) {
+    // Nothing to fetch for a hit that ends the path in a scene without emitters and lights (SceneView::lastSegmentDark): the
+    // shading record, the texture taps and the ten draws of the BSDF sample would add +-0 to `light` and move a ray nobody traces.
+    if (s.lastSegmentDark && bounce == lastBounce && h.hitIdx != kInvalid) return false;
     Surface sf = shadeFetch(s, ray, h, cnt);
     addLights(s, rd, ray, sf, bounce, contribution, light, seed);
     if (!sf.hit) {
@@ -153,23 +156,24 @@ struct FusedArgs {
     uint32_t* result;
     float4* radiance;
     const okrt_render_data* rdDev;  // the same RenderData in device memory: read where it is used instead of being held in SGPRs across the tile loop
+    uint32_t terminalNext;    // 1 = the survivors' next segment is the last one of a scene where a hit there adds nothing (traceKernel MODE 1)
 };
 
 // ---- launch wrappers (one per kernel family; `count` selects the variant that feeds okrt_counters) --------------------
 void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames);
-void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
+void launchTrace(bool count, int mode, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
                  RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals);
 void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,
                   const okrt_render_data& rd, const TileView& tile, RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames,
                   unsigned long long* counters, unsigned long long* rayTotals, const FusedArgs& fa);
 void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
                  RayQueue qIn, HitBuffer hb, const ShardView& in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce, uint32_t lastBounce,
-                 float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters);
+                 float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters, uint32_t terminalNext);
+// the misses of a last segment traced with traceKernel MODE 1 / 2: environment lookup into the pixel's radiance slot
+void launchMiss(dim3 grid, hipStream_t stream, const SceneView& s, RayQueue qIn, const ShardView& in, float4* radiance);
 void launchSetRenderData(hipStream_t stream, const okrt_render_data& rd, okrt_render_data* dst);
 void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t pixels, uint32_t frames, const float4* radiance, float4* accum,
                       uint32_t* result);
-// diagnostic (OKRT_FAST_SORT, okrt_fast_sort.hip): `dst` = the rays of `src` fully sorted by coherence key inside each shard
-bool sortQueue(uint32_t slot, uint32_t mode, hipStream_t stream, const uint4* nodes, RayQueue src, RayQueue dst, const ShardView& sv, uint32_t items, std::string& err);
 void launchKatQueue(hipStream_t stream, bool collect, uint32_t n, const float* in, uint32_t inFloats, float* out, uint32_t outFloats, RayQueue q, HitBuffer hb,
                     uint32_t cap, uint32_t* counts);
 void launchFastKat(hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s, uint32_t n, const float* in, uint32_t inFloats,

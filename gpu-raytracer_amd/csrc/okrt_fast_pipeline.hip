@@ -31,6 +31,7 @@
 //     for bit; only equal-distance ties may resolve to a different triangle.
 // The kernels live in okrt_fast_trace.hip (traversal) and okrt_fast_shade.hip (generation, shading, accumulation);
 // this file owns the device-resident state and the launch sequence.
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -46,8 +47,10 @@ namespace {
 
 // OKRT_OPT_DEBUG_FAIL_ALLOC: the n-th queue allocation from now on fails as the allocator would (test hook for the
 // launch-set split; 0 = off)
-int g_failAllocIn = 0;
-bool g_failArmed = false;  // only the allocations of a launch set count (launchFast arms it), not the structure build
+// (contexts of one process may be driven from several threads — bench.py --gpus N enqueues every rank's launch set from its
+// own thread — so the countdown is atomic and the arming belongs to the thread that is inside ensureQueues)
+std::atomic<int> g_failAllocIn{0};
+thread_local bool g_failArmed = false;  // only the allocations of a launch set count (launchFast arms it), not the structure build
 struct FailAllocScope {
     FailAllocScope() { g_failArmed = true; }
     ~FailAllocScope() { g_failArmed = false; }
@@ -58,7 +61,8 @@ bool devAlloc(T** p, size_t n, std::string& err) {
     if (*p) hipFree(*p);
     *p = nullptr;
     if (!n) return true;
-    hipError_t e = (g_failArmed && g_failAllocIn > 0 && --g_failAllocIn == 0) ? hipErrorOutOfMemory : hipMalloc((void**)p, n * sizeof(T));
+    const bool refuse = g_failArmed && g_failAllocIn.load(std::memory_order_relaxed) > 0 && g_failAllocIn.fetch_sub(1) == 1;
+    hipError_t e = refuse ? hipErrorOutOfMemory : hipMalloc((void**)p, n * sizeof(T));
     if (e != hipSuccess) {
         // a failed hipMalloc stays behind as the thread's "last error": taken out here, or the hipGetLastError() after the
         // NEXT (successful, smaller) launch set would report this one
@@ -194,12 +198,13 @@ bool fastKatTrace(FastScene* fs, const SceneView& s, const okrt_render_data& rd,
         e = hipMemsetAsync(counts, 0, countWords * sizeof(uint32_t), stream);
         if (e == hipSuccess) e = hipMemsetAsync(hb.h, 0xFF, items * sizeof(float4), stream);
         if (e == hipSuccess) e = hipMemsetAsync(hb.tri, 0xFF, items * sizeof(uint32_t), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(totals, 0, 2 * sizeof(unsigned long long), stream);
     }
     if (ok && e == hipSuccess) {
         launchKatQueue(stream, false, n, in, inFloats, out, outFloats, q, hb, cap, counts);
         const FastView fv{fs->nodes.p, fs->tris.p, overflow, fs->overflowCap, (uint32_t)(fs->numNodes * sizeof(Node4Q)), (uint32_t)(fs->numTris * sizeof(Tri48))};
         const ShardView sv{cap, 0u, kBatch, 1u, counts, counts + kShards * kCursorStride};
-        launchTrace(false, dim3(fs->traceBlocks), stream, fv, s, rd, TileView{}, q, hb, sv, 0u, nullptr, totals);
+        launchTrace(false, 0, dim3(fs->traceBlocks), stream, fv, s, rd, TileView{}, q, hb, sv, 0u, nullptr, totals);
         launchKatQueue(stream, true, n, in, inFloats, out, outFloats, q, hb, cap, counts);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the buffers are released below
@@ -212,7 +217,7 @@ bool fastKatTrace(FastScene* fs, const SceneView& s, const okrt_render_data& rd,
     return ok;
 }
 
-void fastDebugFailAlloc(int nth) { g_failAllocIn = nth; }
+void fastDebugFailAlloc(int nth) { g_failAllocIn.store(nth); }
 
 void fastSetQueueBudget(FastScene** scene, size_t bytes) {
     if (!*scene) *scene = new FastScene();
@@ -286,8 +291,7 @@ LaunchStatus ensureQueues(FastScene& fs, FastScene::LaunchSlot& ls, const SceneV
     // 132 bytes per ray and frame in flight. Per pixel and frame of a multi-frame set: a 16-byte radiance slot.
     static const bool envPacket0 = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused0 = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
-    static const uint32_t envSort0 = getenv("OKRT_FAST_SORT") ? (uint32_t)atoi(getenv("OKRT_FAST_SORT")) : 0u;  // diagnostic: sorted copy of queue 1 lives in queue 0
-    const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2 || envSort0;
+    const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2;
     const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 || frameSlots ? (size_t)t.rows * t.W * frames * 16 : 0);
     if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
         err = "launch set exceeds the queue memory budget";
@@ -384,14 +388,17 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     mark();
     static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
-    static const uint32_t envSort = getenv("OKRT_FAST_SORT") ? (uint32_t)atoi(getenv("OKRT_FAST_SORT")) : 0u;
     const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
     const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
     // the launch set's RenderData in device memory, written by a kernel from its by-value argument: stream-ordered after
     // the previous launch set's readers, and no pageable-memory staging on the host side of an asynchronous call
     launchSetRenderData(stream, rd, ls.rdDev);
-    const FusedArgs fa{perFrame, ls.q[1], ls.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, ls.rdDev};
+    // The last segment of a scene in which a hit there adds nothing (SceneView::lastSegmentDark, radiance kept in frame slots):
+    // the kernel that appends its rays settles the hits in advance, traceKernel stores hit-or-miss, missKernel shades the misses.
+    const bool terminal = s.lastSegmentDark && lastBounce >= 1 && radiance != nullptr && !cnt;
+    const int terminalMode = s.lastSegmentAnyHit ? 2 : 1;
+    const FusedArgs fa{perFrame, ls.q[1], ls.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, ls.rdDev, (terminal && lastBounce == 1) ? 1u : 0u};
     const uint32_t pixels32 = (uint32_t)pixels;
     // the one step of a launch set that touches the accumulation: after the previous set's (another stream may carry it)
     auto orderedAccumulate = [&]() {
@@ -403,26 +410,27 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
         launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, fa);
         mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
-        if (envSort && lastBounce == 1 && !sortQueue(order.slot, envSort, stream, fs.nodes.p, ls.q[1], ls.q[0], shards(1, false), (uint32_t)items, err)) return LaunchStatus::Device;
     } else {
         // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade
         launchGenerate(sg, stream, rd, t, ls.q[0], perFrame, frames);
         if (packet) launchPacket(cnt, false, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, fa);
-        else launchTrace(cnt, tg, stream, fv, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals);
+        else launchTrace(cnt, 0, tg, stream, fv, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals);
         mark();
         launchShade(true, cnt, sg, stream, s, rd, t, ls.q[0], ls.hb, shards(0, true), ls.q[1], ls.counts + kShards * kCursorStride, 0u, lastBounce, accum, result,
-                    radiance, counters);
+                    radiance, counters, fa.terminalNext);
     }
     if (lastBounce == 0 && radiance) orderedAccumulate();
     mark();
     // segments 1..lastBounce: queue b lives in q[b & 1]
     for (uint32_t b = 1; b <= lastBounce; ++b) {
-        RayQueue& qin = (envSort && lastBounce == 1 && packet && envFused) ? ls.q[0] : ls.q[b & 1];  // (diagnostic: the sorted copy)
+        RayQueue& qin = ls.q[b & 1];
         RayQueue& qout = ls.q[(b + 1) & 1];
-        launchTrace(cnt, tg, stream, fv, s, rd, t, qin, ls.hb, shards(b, false), 0u, counters, rayTotals);
+        const bool last = terminal && b == lastBounce;
+        launchTrace(cnt, last ? terminalMode : 0, tg, stream, fv, s, rd, t, qin, ls.hb, shards(b, false), 0u, counters, rayTotals);
         mark();
-        launchShade(false, cnt, sg, stream, s, rd, t, qin, ls.hb, shards(b, false), qout, ls.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum,
-                    result, radiance, counters);
+        if (last) launchMiss(sg, stream, s, qin, shards(b, false), radiance);
+        else launchShade(false, cnt, sg, stream, s, rd, t, qin, ls.hb, shards(b, false), qout, ls.counts + (b + 1) * kShards * kCursorStride, b, lastBounce, accum,
+                         result, radiance, counters, (terminal && b + 1 == lastBounce) ? 1u : 0u);
         if (b == lastBounce && radiance) orderedAccumulate();
         mark();
     }

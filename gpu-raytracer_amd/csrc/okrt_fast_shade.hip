@@ -30,7 +30,7 @@ template <bool FIRST, bool COUNT>
 __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data rd, TileView tile, RayQueue qIn, HitBuffer hb,
                                                   ShardView in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce,
                                                   uint32_t lastBounce, float4* accum, uint32_t* result, float4* radiance,
-                                                  unsigned long long* counters) {
+                                                  unsigned long long* counters, uint32_t terminalNext) {
     // positions are [shard][cap]; cap is a multiple of 256, so a block (and a wave) never straddles shards
     const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const uint32_t shard = (blockIdx.x * 256) / in.cap;
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
         stStream(&qOut.b[o], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
         stStream(&qOut.c[o], make_float4(contribution.x, contribution.y, contribution.z, light.x));
         stStream(&qOut.d[o], make_float2(light.y, light.z));
+        if (terminalNext) stStream(&radiance[pix], make_float4(0.f, 0.f, 0.f, 1.f));  // (see tracePacketKernel: the next segment is traced by traceKernel MODE 1)
     }
     if (COUNT && counters) {
         uint32_t vals[5] = {(FIRST && valid) ? 1u : 0u, cnt.meshHits, cnt.sphereHits, cnt.texTaps, cnt.envTaps};
@@ -101,6 +102,19 @@ __global__ __launch_bounds__(256) void shadeKernel(SceneView s, okrt_render_data
             if (lane == 0 && v) atomicAdd(&counters[slot[k]], (unsigned long long)v);
         }
     }
+}
+
+// The misses of the last segment when traceKernel ran in MODE 1 / 2 (hits were settled by the kernel that appended the ray):
+// RaytracerCS.hlsl:489-493 with the +0 radiance such a path carries (SceneView::lastSegmentDark).
+__global__ __launch_bounds__(256) void missKernel(SceneView s, RayQueue qIn, ShardView in, float4* radiance) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t shard = (blockIdx.x * 256) / in.cap;
+    if (i >= shard * in.cap + in.count(shard)) return;
+    if (ldStream(reinterpret_cast<const uint32_t*>(&qIn.d[i])) != kInvalid) return;  // (+0 = still the radiance the path carried: it hit something)
+    const float4 A = ldStream(&qIn.a[i]), B = ldStream(&qIn.b[i]), C = ldStream(&qIn.c[i]);
+    PathCounters cnt = {};
+    const V3 light = fma3(sampleEnvironment(s, mk(A.w, B.x, B.y), cnt), mk(C.x, C.y, C.z), mk(0.f, 0.f, 0.f));
+    stStream(&radiance[__float_as_uint(B.w)], make_float4(light.x, light.y, light.z, 1.f));
 }
 
 // Adds the radiance slots of `frames` frames to the accumulation IN FRAME ORDER and resolves with the last frame's
@@ -137,12 +151,16 @@ void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, c
 
 void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
                  RayQueue qIn, HitBuffer hb, const ShardView& in, RayQueue qOut, uint32_t* outCounts, uint32_t bounce, uint32_t lastBounce,
-                 float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters) {
+                 float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters, uint32_t terminalNext) {
     const dim3 tb(256);
-    if (first && count) hipLaunchKernelGGL((shadeKernel<true, true>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
-    else if (first) hipLaunchKernelGGL((shadeKernel<true, false>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
-    else if (count) hipLaunchKernelGGL((shadeKernel<false, true>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
-    else hipLaunchKernelGGL((shadeKernel<false, false>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters);
+    if (first && count) hipLaunchKernelGGL((shadeKernel<true, true>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters, terminalNext);
+    else if (first) hipLaunchKernelGGL((shadeKernel<true, false>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters, terminalNext);
+    else if (count) hipLaunchKernelGGL((shadeKernel<false, true>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters, terminalNext);
+    else hipLaunchKernelGGL((shadeKernel<false, false>), grid, tb, 0, stream, s, rd, tile, qIn, hb, in, qOut, outCounts, bounce, lastBounce, accum, result, radiance, counters, terminalNext);
+}
+
+void launchMiss(dim3 grid, hipStream_t stream, const SceneView& s, RayQueue qIn, const ShardView& in, float4* radiance) {
+    hipLaunchKernelGGL(missKernel, grid, dim3(256), 0, stream, s, qIn, in, radiance);
 }
 
 void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t pixels, uint32_t frames, const float4* radiance, float4* accum,

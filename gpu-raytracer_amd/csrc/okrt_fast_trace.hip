@@ -45,7 +45,12 @@ __device__ __forceinline__ uint2 ldsRead64(const uint2* p) {
 //   ... 8 waves per SIMD (64 VGPRs: 48-56 B of scratch in the loop)                               0.659 / 0.383
 //   this loop with buffer loads instead of 64-bit global addresses                               0.233 / 0.134
 //   ... triangles (and nodes below the first visits) with sc1 / nt cache policy, to keep them out of L1   0.242-0.47 / 0.18-0.41
-template <bool COUNT>
+// MODE: what a finished ray leaves behind. 0 = the 20-byte hit record. 1 = hit-or-miss only, for the LAST segment of a scene in
+// which a hit there adds nothing (SceneView::lastSegmentDark): the kernel that appended the ray wrote
+// the radiance a hit ends with into its pixel's slot, so only a MISS stores anything here (the bits of kInvalid over the first
+// word of its queue entry's `d` pair, which holds the +0 radiance such a path carries; missKernel shades those) — the traversal itself is the same closest-hit walk. 2 = as 1, and the ray ends at its first accepted hit
+// (OKRT_OPT_LAST_SEGMENT_ANY_HIT, off by default, never the graded kernel).
+template <bool COUNT, int MODE>
 __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(OKRT_TRACE_WAVES, OKRT_TRACE_WAVES))) void traceKernel(
     FastView fv, SceneView s, okrt_render_data rd, TileView tile, RayQueue q, HitBuffer hb, ShardView sv, uint32_t cameraFrames, unsigned long long* counters,
     unsigned long long* rayTotals) {
@@ -125,8 +130,12 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             stRefill++;
 #endif
             if (cur == kDone && leaf == kDone && rayIdx != kInvalid) {
-                stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
-                stStream(&hb.tri[rayIdx], hitTri);
+                if (MODE == 0) {
+                    stStream(&hb.h[rayIdx], make_float4(best, hbu, hbv, __uint_as_float(hitIdx)));
+                    stStream(&hb.tri[rayIdx], hitTri);
+                } else if (hitIdx == kInvalid) {
+                    stStream(reinterpret_cast<uint32_t*>(&q.d[rayIdx]), kInvalid);
+                }
                 rayIdx = kInvalid;
             }
             for (int round = 0; round < 2 && !exhausted; ++round) {
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                             }
                         }
                         sp = 0;
-                        cur = 0;  // root node
+                        cur = (MODE == 2 && hitIdx != kInvalid) ? kDone : 0u;  // root node (any-hit: a sphere hit already ends the ray)
                         leaf = kDone;
                     }
                 }
@@ -319,6 +328,10 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                     hbv = bv;
                     hitTri = d0.w;
                     hitIdx = d1.w;
+                    if (MODE == 2) {  // first accepted hit: done (the stack is simply abandoned)
+                        sp = 0;
+                        triJ = 15u;
+                    }
                 }
             }
             if (++triJ > ((leaf >> 27) & 15u)) {  // count - 1 is stored
@@ -610,6 +623,8 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                     stStream(&fa.qOut.b[o], make_float4(ray.direction.y, ray.direction.z, __uint_as_float(seed), __uint_as_float(pix)));
                     stStream(&fa.qOut.c[o], make_float4(contribution.x, contribution.y, contribution.z, light.x));
                     stStream(&fa.qOut.d[o], make_float2(light.y, light.z));
+                    // the next segment is the last and a hit there adds nothing (traceKernel MODE 1): what a hit ends with, now
+                    if (fa.terminalNext) stStream(&fa.radiance[pix], make_float4(0.f, 0.f, 0.f, 1.f));
                 }
             }
         }
@@ -750,11 +765,13 @@ void launchKatQueue(hipStream_t stream, bool collect, uint32_t n, const float* i
     hipLaunchKernelGGL(katQueueKernel, dim3((std::max(n, kShards) + 255) / 256), dim3(256), 0, stream, collect, n, in, inFloats, out, outFloats, q, hb, cap, counts);
 }
 
-void launchTrace(bool count, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
+void launchTrace(bool count, int mode, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
                  RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals) {
     const dim3 tb(kTraceThreads);
-    if (count) hipLaunchKernelGGL((traceKernel<true>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
-    else hipLaunchKernelGGL((traceKernel<false>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+    if (mode == 2) hipLaunchKernelGGL((traceKernel<false, 2>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+    else if (mode == 1) hipLaunchKernelGGL((traceKernel<false, 1>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+    else if (count) hipLaunchKernelGGL((traceKernel<true, 0>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
+    else hipLaunchKernelGGL((traceKernel<false, 0>), grid, tb, 0, stream, fv, s, rd, tile, q, hb, sv, cameraFrames, counters, rayTotals);
 }
 
 void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,

@@ -177,7 +177,21 @@ typedef enum okrt_option {
      * rank; a full 1080p frame, where it would cost 4.5 %, is not cut). Same framebuffers bit for bit.
      * Footprint: the queues of up to FOUR launch sets of up to n frames (default: 4 x 0.76 GB at 1080p). 0 = one launch
      * set at a time. */
-    OKRT_OPT_PIPELINE = 8
+    OKRT_OPT_PIPELINE = 8,
+    /* 1 (default) = work whose result is provably +-0 is not executed on the LAST path segment. When the frame's RenderData
+     * holds no light (RaytracerCS.hlsl:448-487 never runs), every uploaded Material (t6, t7) has emission colour * power ==
+     * (0, 0, 0) and |albedo| <= 1, a hit on the last segment contributes `emission * contribution * (1 - transparencyFactor)`
+     * = +-0 (:509-510) and the sampled bounce direction is never traced: the fast pipeline then skips the shading record, the
+     * texture taps and the BSDF draws of those hits, the bounce-ray kernel stores only hit-or-miss, and only the misses (the
+     * environment lookup of :489-493) are shaded. Framebuffers are bit-identical to 0 = every segment shaded in full
+     * (tests/test_gpu_properties.py); any emitter, any light, an albedo outside [-1, 1] or a NaN in a material, and
+     * OKRT_OPT_COUNTERS (tex_taps / mesh_hits count the reference's work) select the full path by themselves. */
+    OKRT_OPT_LAST_SEGMENT_SHORTCUT = 9,
+    /* 1 = (only where the shortcut above applies) the last segment's ray ends at the FIRST accepted hit instead of the closest:
+     * hit-or-miss is all the picture needs there, so framebuffers stay bit-identical, but those rays are no longer the
+     * closest-hit segments the Mrays/s metric counts — bench.py reports this mode under its own name, never as the
+     * headline. Default 0. */
+    OKRT_OPT_LAST_SEGMENT_ANY_HIT = 10
 } okrt_option;
 
 #define OKRT_BUILDER_HOST 0
@@ -331,6 +345,9 @@ typedef struct okrt_build_info {
  * LARGER local-space box distance with the world-space best hit (quirk Q3, RaytracerCS.hlsl:285 vs :311-318) and drops
  * geometry it should test; OKRT_TRAVERSAL_FAST returns the true closest hit instead (documented deviation) */
 #define OKRT_BUILD_FLAG_SHRUNK_INSTANCES 2u
+/* every uploaded Material (t6, t7) has emission colour * power == (0, 0, 0) and |albedo| <= 1: the material half of the condition
+ * under which OKRT_OPT_LAST_SEGMENT_SHORTCUT applies (the other half is a RenderData without lights) */
+#define OKRT_BUILD_FLAG_DARK_MATERIALS 4u
 okrt_status okrt_get_build_info(okrt_ctx* ctx, okrt_build_info* out);
 /* Test / tooling access: copies the derived structure to the host (64 B per node, 48 B per triangle; layouts in
  * gpu-raytracer_amd/csrc/okrt_fast.h). Either pointer may be NULL. OKRT_ERR_STATE if nothing is built. */

@@ -1,0 +1,114 @@
+// issue_rate — how many wave-instructions per cycle one SIMD of an MI355X (gfx950) starts, by kind and by resident waves.
+// The traversal kernels are "issue-bound" by their own counters (profiles/r05_pmc_*: VALU + SALU instructions per SIMD quad-cycle); this
+// tool measures what the denominators of that statement are, in isolation: a loop of INDEPENDENT instructions of one kind (or an
+// alternation of two kinds), W waves per SIMD, every CU busy, no memory traffic.
+//   fma        v_fma_f32                 (the slab arithmetic, Moeller-Trumbore)
+//   cndmask    v_cndmask_b32             (the select-based child sort)
+//   minmax     v_max_f32 / v_min_f32     (slab reduction)
+//   cvt        v_cvt_f32_ubyte0          (8-bit plane decode)
+//   salu       s_add_u32 / s_and_b32     (what the packet kernel's scalar sort and the per-iteration bookkeeping are made of)
+//   fma+salu   one of each per pair      (do the vector and the scalar port issue side by side?)
+// Output: instructions per cycle per SIMD = N / (s_memtime delta of the wave that ran longest), and per quad-cycle (x4: the unit of the
+// SQ_* counters). build: hipcc --offload-arch=gfx950 -O3 -o tools/calib/issue_rate tools/calib/issue_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int kUnroll = 64;  // instructions (or pairs) per loop trip
+
+template <int KIND>
+__global__ __launch_bounds__(256) void issueKernel(uint32_t trips, unsigned long long* cycles, float* sink) {
+    float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float m = 1.0000001f, c = 1e-9f;
+    uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (uint32_t t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int k = 0; k < kUnroll / 8; ++k) {
+            if (KIND == 0) {
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (KIND == 1) {
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");
+            } else if (KIND == 2) {
+                asm volatile("v_max_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n"
+                             "v_max_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_min_f32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            } else if (KIND == 3) {
+                asm volatile("v_cvt_f32_ubyte0 %0, %0\n v_cvt_f32_ubyte0 %1, %1\n v_cvt_f32_ubyte0 %2, %2\n v_cvt_f32_ubyte0 %3, %3\n"
+                             "v_cvt_f32_ubyte0 %4, %4\n v_cvt_f32_ubyte0 %5, %5\n v_cvt_f32_ubyte0 %6, %6\n v_cvt_f32_ubyte0 %7, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 4) {
+                asm volatile("s_add_u32 %0, %0, 3\n s_and_b32 %1, %1, 0xffff\n s_add_u32 %2, %2, 5\n s_and_b32 %3, %3, 0xfff\n"
+                             "s_add_u32 %0, %0, 7\n s_and_b32 %1, %1, 0xff\n s_add_u32 %2, %2, 9\n s_and_b32 %3, %3, 0xf"
+                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+            } else {  // 5: fma + salu interleaved (8 of each per block = 16 instructions)
+                asm volatile("v_fma_f32 %0, %0, %12, %13\n s_add_u32 %8, %8, 3\n v_fma_f32 %1, %1, %12, %13\n s_and_b32 %9, %9, 0xffff\n"
+                             "v_fma_f32 %2, %2, %12, %13\n s_add_u32 %10, %10, 5\n v_fma_f32 %3, %3, %12, %13\n s_and_b32 %11, %11, 0xfff\n"
+                             "v_fma_f32 %4, %4, %12, %13\n s_add_u32 %8, %8, 7\n v_fma_f32 %5, %5, %12, %13\n s_and_b32 %9, %9, 0xff\n"
+                             "v_fma_f32 %6, %6, %12, %13\n s_add_u32 %10, %10, 9\n v_fma_f32 %7, %7, %12, %13\n s_and_b32 %11, %11, 0xf"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
+                             : "v"(m), "v"(c) : "scc");
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 ^ s1 ^ s2 ^ s3);
+    if (r == 1.2345e-30f) sink[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+template <int KIND>
+static void measure(const char* name, int perPair, int cus, unsigned long long* dCycles, float* sink) {
+    const uint32_t trips = 4000;
+    for (int wavesPerSimd : {1, 2, 4, 7, 8}) {
+        // one block = 4 waves = one wave per SIMD of the CU it lands on; W blocks per CU fill W waves per SIMD
+        const int blocks = cus * wavesPerSimd;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        issueKernel<KIND><<<blocks, 256>>>(trips, dCycles, sink);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        issueKernel<KIND><<<blocks, 256>>>(trips, dCycles, sink);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> cyc((size_t)blocks * 4);
+        CK(hipMemcpy(cyc.data(), dCycles, cyc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long worst = 0;
+        double mean = 0;
+        for (auto c : cyc) { worst = c > worst ? c : worst; mean += (double)c; }
+        mean /= (double)cyc.size();
+        // a SIMD ran wavesPerSimd waves (if the dispatcher spread the blocks evenly), each trips * kUnroll * perPair instructions
+        const double insts = (double)wavesPerSimd * trips * kUnroll * perPair;
+        printf("%-9s %5d %12.3f %14.0f %14.0f %12.3f %12.3f\n", name, wavesPerSimd, ms, mean, (double)worst, insts / mean, 4.0 * insts / mean);
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+}
+
+int main() {
+    int dev = 0, cus = 0;
+    CK(hipGetDevice(&dev));
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    unsigned long long* dCycles;
+    float* sink;
+    CK(hipMalloc((void**)&dCycles, (size_t)cus * 8 * 4 * sizeof(unsigned long long)));
+    CK(hipMalloc((void**)&sink, (size_t)cus * 8 * 256 * sizeof(float)));
+    printf("# %d CUs; %d-instruction unrolled loop of independent instructions, 4000 trips, 256-thread blocks (one wave per SIMD each), W blocks per CU\n", cus, kUnroll);
+    printf("%-9s %5s %12s %14s %14s %12s %12s\n", "kind", "W", "kernel ms", "mean cyc/wave", "worst cyc/wave", "inst/cyc/SIMD", "inst/quad-cyc");
+    measure<0>("fma", 1, cus, dCycles, sink);
+    measure<1>("cndmask", 1, cus, dCycles, sink);
+    measure<2>("minmax", 1, cus, dCycles, sink);
+    measure<3>("cvt", 1, cus, dCycles, sink);
+    measure<4>("salu", 1, cus, dCycles, sink);
+    measure<5>("fma+salu", 2, cus, dCycles, sink);
+    return 0;
+}

@@ -42,13 +42,18 @@ PASSES = [
     ("sq", ["--pmc", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
             "SQ_WAIT_INST_ANY", "--kernel-trace"]),
     ("l1", ["--pmc", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "--kernel-trace"]),
+    # issue-rate roofline (round 5): what the scalar unit, the vector-memory and the LDS instructions take besides the VALU of pass `sq`,
+    # and the clock: GRBM_GUI_ACTIVE = busy cycles summed over the 8 XCDs (GRBM has its own 2 slots: it rides this pass)
+    ("sq2", ["--pmc", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY",
+             "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace"]),
 ]
-FAMILIES = ("tracePacketKernel", "traceKernel", "shadeKernel", "accumulateKernel", "generateKernel", "renderReferenceOrder")
+FAMILIES = ("tracePacketKernel", "traceKernel", "shadeKernel", "missKernel", "accumulateKernel", "generateKernel", "renderReferenceOrder")
+SIMDS = 256 * 4  # MI355X: 256 CUs x 4 SIMDs
 
 
 def family(name):
     """(family, counting variant?) of a kernel name; None for kernels that are not part of the frame."""
-    m = re.search(r"(tracePacketKernel|traceKernel|shadeKernel|accumulateKernel|generateKernel|renderReferenceOrder)(<([^>]*)>)?", name)
+    m = re.search(r"(tracePacketKernel|traceKernel|shadeKernel|missKernel|accumulateKernel|generateKernel|renderReferenceOrder)(<([^>]*)>)?", name)
     if not m:
         return None, False
     args = [a.strip() for a in (m.group(3) or "").split(",")] if m.group(3) else []
@@ -62,7 +67,7 @@ def main():
     ap.add_argument("--workload", default="sponza")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--out", default="gpurun_out/pmc")
-    ap.add_argument("--passes", default="stats,fetch,write,sq,l1")
+    ap.add_argument("--passes", default="stats,fetch,write,sq,l1,sq2")
     args = ap.parse_args()
     import bench
     args.out = os.path.abspath(args.out)  # rocprofv3 runs from /tmp
@@ -92,12 +97,14 @@ def main():
             if fam and not counting:
                 dur[fam].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
-    for name in ("fetch", "write", "sq", "l1"):
+    for name in ("fetch", "write", "sq", "l1", "sq2"):
         for f in glob.glob(os.path.join(args.out, f"{tag}_{name}", "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 fam, counting = family(r["Kernel_Name"])
                 if fam and not counting:
-                    ctr[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    # (SQ_INSTS_VALU rides both SQ passes: pass sq2's copy sits beside GRBM_GUI_ACTIVE, i.e. the same launches' clock)
+                    cname = r["Counter_Name"] + ("@sq2" if name == "sq2" and r["Counter_Name"] == "SQ_INSTS_VALU" else "")
+                    ctr[fam][cname].append(float(r["Counter_Value"]))
     kernels = {}
     for fam in FAMILIES:
         if fam not in dur and fam not in ctr:
@@ -110,7 +117,7 @@ def main():
         # the kernel's coalesced 16-B-per-lane stream reads (bench.py knows them from the ray / pixel counts): counted at half
         stream = 0.0
         for bk in ((bench_lines.get("stats") or {}).get("roofline") or {}).get("kernels", []):
-            if bk["kernel"].split(" ")[0].split("<")[0] == fam or (fam == "accumulateKernel" and False):
+            if bk["kernel"].split(" ")[0].split("<")[0] == fam:
                 stream = float(bk.get("stream_read_bytes_per_launch", 0))
         add_back = min(stream, 2.0 * fetch) / 2.0
         k = {"launches_seen": len(dur.get(fam, [])), "launch_ms": round(sum(dur[fam]) / len(dur[fam]), 4) if dur.get(fam) else None,
@@ -124,15 +131,44 @@ def main():
                 k["wait_any_share"] = round(avg.get("SQ_WAIT_ANY", 0.0) / wc, 4)
                 k["wait_inst_share"] = round(avg.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
                 k["valu_inst_per_wave_cycle"] = round(avg.get("SQ_INSTS_VALU", 0.0) / wc, 4)
+        # Issue-rate roofline. A SIMD gets one issue slot per quad-cycle (4 shader clocks) and can start at most one instruction of
+        # each kind in it, so over a kernel of Q quad-cycles (GRBM_GUI_ACTIVE / 8 XCDs / 4) the chip has SIMDS * Q slots per kind:
+        #   *_issue_frac = instructions of that kind / slots        (how full the kind's issue port is)
+        #   *_busy_frac  = SQ_ACTIVE_INST_* / slots                 (quad-cycles some wave spent executing that kind; VALUBusy / SALUBusy
+        #                                                            of the gfx9 derived-counter files; an instruction may hold its unit for
+        #                                                            more than one slot: transcendentals 2, wave64 DP more)
+        # Both passes' duration may differ slightly from an un-profiled launch (the guide's DVFS note): fractions, not times, are kept.
+        gui = avg.get("GRBM_GUI_ACTIVE", 0.0)
+        if gui:
+            slots = SIMDS * (gui / 8.0 / 4.0)
+            k["kernel_quad_cycles"] = round(gui / 8.0 / 4.0, 1)
+            if k["launch_ms"]:
+                k["clock_ghz_under_profile"] = round(gui / 8.0 / (k["launch_ms"] * 1e-3) / 1e9, 3)
+            if avg.get("SQ_INSTS_VALU@sq2"):
+                k["valu_issue_frac"] = round(avg["SQ_INSTS_VALU@sq2"] / slots, 4)
+            for src, dst in (("SQ_INSTS_SALU", "salu_issue_frac"), ("SQ_INSTS_SMEM", "smem_issue_frac"), ("SQ_INSTS_LDS", "lds_issue_frac"),
+                             ("SQ_ACTIVE_INST_SCA", "scalar_busy_frac"), ("SQ_ACTIVE_INST_ANY", "any_busy_frac")):
+                if src in avg:
+                    k[dst] = round(avg[src] / slots, 4)
+            if "SQ_INSTS_VMEM_RD" in avg:
+                k["vmem_issue_frac"] = round((avg["SQ_INSTS_VMEM_RD"] + avg.get("SQ_INSTS_VMEM_WR", 0.0)) / slots, 4)
+            # (pass sq has no clock of its own: SQ_ACTIVE_INST_VALU is scaled by the two passes' SQ_INSTS_VALU, equal up to run-to-run noise)
+            if avg.get("SQ_ACTIVE_INST_VALU") and avg.get("SQ_INSTS_VALU") and avg.get("SQ_INSTS_VALU@sq2"):
+                k["valu_busy_frac"] = round(avg["SQ_ACTIVE_INST_VALU"] * (avg["SQ_INSTS_VALU@sq2"] / avg["SQ_INSTS_VALU"]) / slots, 4)
         if avg.get("TCP_TCC_READ_REQ_sum"):
             k["l2_read_requests_per_launch"] = avg["TCP_TCC_READ_REQ_sum"] * per_set  # 128-byte lines
             k["l1_accesses_per_launch"] = avg.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) * per_set
             if k["launch_ms"]:
                 k["l2_read_requests_per_s"] = round(k["l2_read_requests_per_launch"] / (k["launch_ms"] * 1e-3), 0)
         kernels[fam] = k
-    if "shadeKernel" in kernels and "accumulateKernel" in kernels:  # bench.py times them as one interval
-        a, b = kernels["shadeKernel"], kernels["accumulateKernel"]
-        kernels["shadeKernel"] = dict(a, hbm_bytes_per_launch=a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"], note="includes accumulateKernel's bytes")
+    for first in ("shadeKernel", "missKernel"):  # bench.py times the last shading kernel and the accumulation as one interval
+        if first in kernels and "accumulateKernel" in kernels:
+            a, b = kernels[first], kernels["accumulateKernel"]
+            # (bench.py gives the pair ONE stream-read figure: the add-back is taken against the pair's pooled FETCH_SIZE)
+            fetch = a["fetch_bytes_raw"] + b["fetch_bytes_raw"]
+            add_back = min(a["stream_read_bytes"], 2.0 * fetch) / 2.0
+            kernels[first] = dict(a, stream_add_back_bytes=add_back, hbm_bytes_per_launch=fetch + add_back + a["write_bytes"] + b["write_bytes"],
+                                  note="includes accumulateKernel's bytes")
     out = {
         "workload": args.workload, "frames_per_launch": args.frames, "source_sha": bench.kernel_source_sha(),
         "command": "rocprofv3 <pass flags> --output-format csv -d <dir> -- " + " ".join(["python3", "bench.py"] + cmd[2:]),
