@@ -22,8 +22,8 @@ TABLE_STRIDE = {0: 36, 1: 132, 2: 36, 5: 48, 6: 84, 7: 232, 8: 32, 9: 32, 10: 48
 OPT_TRAVERSAL, OPT_MAX_BOUNCES, OPT_COUNTERS, OPT_TIMING, OPT_BUILDER, OPT_DEFER, OPT_QUEUE_MEMORY_MB, OPT_DEBUG_FAIL_ALLOC, OPT_PIPELINE = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_LAST_SEGMENT_SHORTCUT, OPT_LAST_SEGMENT_ANY_HIT = 9, 10
 BUILDER_HOST, BUILDER_DEVICE = 0, 1
-TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1
-BUILD_FLAG_SCALED_INSTANCES, BUILD_FLAG_SHRUNK_INSTANCES, BUILD_FLAG_DARK_MATERIALS = 1, 2, 4
+TRAVERSAL_REFERENCE, TRAVERSAL_FAST, TRAVERSAL_AUTO = 0, 1, 2
+BUILD_FLAG_SCALED_INSTANCES, BUILD_FLAG_SHRUNK_INSTANCES, BUILD_FLAG_DARK_MATERIALS, BUILD_FLAG_CAMERA_PER_RAY = 1, 2, 4, 8
 
 
 class RenderData(C.Structure):

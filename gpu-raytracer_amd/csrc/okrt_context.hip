@@ -44,7 +44,8 @@ struct okrt_ctx {
     uint32_t* result = nullptr;
     DeviceBuffer counters;
     bool countersOn = false, timingOn = false;
-    int traversal = OKRT_TRAVERSAL_FAST;
+    int traversal = OKRT_TRAVERSAL_AUTO;  // see effectiveTraversal
+    uint32_t instFlags = 0;               // OKRT_BUILD_FLAG_SCALED / _SHRUNK_INSTANCES of the uploaded t7 (recomputed at upload)
     int maxBounces = 1;
     // SceneView::lastSegmentDark = lastSegmentShortcut && materialsDark && no light in the frame's RenderData && counters off
     bool materialsDark = true;          // every Material in t6 / t7: emission colour * power == (+-0)^3 and |albedo| <= 1 (recomputed at upload)
@@ -64,6 +65,7 @@ struct okrt_ctx {
     uint32_t pending = 0, deferMax = 16;
     bool deferReserved = false;  // the queues of a full deferred launch set are allocated (OOM belongs to the call that defers)
     uint32_t batchLimit = kMaxFramesPerLaunch;  // halved when the queues of a launch set do not fit in memory
+    bool queueBudgetChosen = false;             // the host set OKRT_OPT_QUEUE_MEMORY_MB itself (else: a quarter of the free memory at okrt_resize)
     okrt_render_data pendingRd{};
     bool externalFramebuffers = false, externalStream = false;
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
@@ -106,12 +108,19 @@ okrt_status fail(okrt_ctx* c, okrt_status s, const std::string& msg) {
     return s;
 }
 
+// OKRT_TRAVERSAL_AUTO (the default): the fast pipeline wherever it shows the reference's picture; the reference-order kernel
+// for a scene with a shrunk instance, where the reference drops geometry (quirk Q3) and the fast structure does not.
+int effectiveTraversal(const okrt_ctx* c) {
+    if (c->traversal != OKRT_TRAVERSAL_AUTO) return c->traversal;
+    return (c->instFlags & OKRT_BUILD_FLAG_SHRUNK_INSTANCES) ? OKRT_TRAVERSAL_REFERENCE : OKRT_TRAVERSAL_FAST;
+}
+
 // Executes the deferred frames. Errors of the launch (queue memory) surface at the call that flushes.
 // `frames` consecutive frames of the accumulation loop, as few launch sets as memory allows: a launch set that cannot
 // get its queues (56+ bytes per ray and frame) is retried at half the size, and the limit is remembered.
 LaunchPlanParams planParams(const okrt_ctx* c, bool batchable) {
     return LaunchPlanParams{c->tile.rows, c->W, c->batchLimit, c->pipelineMaxFrames, c->pipelineDepth, c->splitParts, c->splitRays,
-                            c->pipelineOn && !c->externalStream && !c->externalFramebuffers && c->traversal == OKRT_TRAVERSAL_FAST, batchable};
+                            c->pipelineOn && !c->externalStream && !c->externalFramebuffers && effectiveTraversal(c) == OKRT_TRAVERSAL_FAST, batchable};
 }
 
 okrt_status renderBatched(okrt_ctx* c, const okrt_render_data* rd, uint32_t frames, bool batchable) {
@@ -484,6 +493,10 @@ okrt_status okrt_set_table(okrt_ctx* c, okrt_table slot, const void* data, uint3
         }
     }
     if (slot == OKRT_TABLE_SPHERE || slot == OKRT_TABLE_MESH) c->materialsDark = allMaterialsDark(c);
+    if (slot == OKRT_TABLE_MESH) {
+        c->instFlags = instanceFlags(c);
+        c->shrunkWarningDue = (c->instFlags & OKRT_BUILD_FLAG_SHRUNK_INSTANCES) != 0;
+    }
     if (slot == OKRT_TABLE_TRI_POS || slot == OKRT_TABLE_TRI_INFO || slot == OKRT_TABLE_BVH || slot == OKRT_TABLE_OCT || slot == OKRT_TABLE_MESH) {
         c->tablesDirty = true;
         c->fastDirty = true;
@@ -574,7 +587,19 @@ okrt_status okrt_resize(okrt_ctx* c, uint32_t width, uint32_t height) {
     c->W = width;
     c->H = height;
     c->tile = TileView{width, height, height, height, 0, 1};
-    return allocFramebuffers(c);
+    okrt_status s = allocFramebuffers(c);
+    if (s == OKRT_OK && !c->queueBudgetChosen) {
+        // default bound for the ray queues of one launch set (okrt.h, OKRT_OPT_QUEUE_MEMORY_MB): a quarter of what is free now
+        size_t freeB = 0, totalB = 0;
+        if (const char* e = getenv("OKRT_QUEUE_MEMORY_ASSUME_FREE_MB")) freeB = (size_t)strtoull(e, nullptr, 10) << 20;  // test hook
+        else if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = 0, (void)hipGetLastError();
+        if (freeB) {
+            fastSetQueueBudget(&c->fast, std::max<size_t>(freeB / 4, (size_t)1 << 20));
+            c->batchLimit = kMaxFramesPerLaunch;
+            c->deferReserved = false;
+        }
+    }
+    return s;
 }
 
 okrt_status okrt_set_tile(okrt_ctx* c, uint32_t stripe_rows, uint32_t stripe_index, uint32_t stripe_stride) {
@@ -631,7 +656,7 @@ static void warnShrunkInstancesOnce(okrt_ctx* c);
 // and tables are still validated here, so the call that passes bad data is the one that fails.
 okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
-    const bool defer = c->deferMax > 1 && !c->externalFramebuffers && !c->externalStream && c->traversal == OKRT_TRAVERSAL_FAST &&
+    const bool defer = c->deferMax > 1 && !c->externalFramebuffers && !c->externalStream && effectiveTraversal(c) == OKRT_TRAVERSAL_FAST &&
                        rd->debugMode == 0 && rd->accumulationEnabled == 1;
     if (!defer) {
         OKRT_FLUSH_KEEP_PIPELINE(c);
@@ -641,7 +666,6 @@ okrt_status okrt_render(okrt_ctx* c, const okrt_render_data* rd) {
     if (s != OKRT_OK) return s;
     OKRT_HIP(c, hipSetDevice(c->device));
     if ((s = ensureTables(c)) != OKRT_OK || (s = ensureFast(c)) != OKRT_OK) return s;
-    warnShrunkInstancesOnce(c);
     if (!c->deferReserved && c->tile.rows && c->pending >= 1) {
         // the host is looping (a second frame waits): what the deferred frames will need when they are finally launched is
         // allocated NOW, so that an allocator refusal is reported inside the loop, by a call that defers, and not by whichever
@@ -684,7 +708,7 @@ okrt_status okrt_render_frames(okrt_ctx* c, const okrt_render_data* rd, uint32_t
     if (!c || !rd) return OKRT_ERR_INVALID_ARG;
     OKRT_FLUSH_KEEP_PIPELINE(c);
     if (!frames) return OKRT_OK;
-    const bool batchable = c->traversal == OKRT_TRAVERSAL_FAST && rd->debugMode == 0 && rd->accumulationEnabled == 1;
+    const bool batchable = effectiveTraversal(c) == OKRT_TRAVERSAL_FAST && rd->debugMode == 0 && rd->accumulationEnabled == 1;
     return renderBatched(c, rd, frames, batchable);
 }
 
@@ -719,18 +743,20 @@ static okrt_status ensureFast(okrt_ctx* c) {
     c->fastDirty = false;
     c->fastGeometryDirty = false;
     c->deferReserved = false;  // (the spill slab follows the tree depth)
-    c->shrunkWarningDue = (instanceFlags(c) & OKRT_BUILD_FLAG_SHRUNK_INSTANCES) != 0;
     return OKRT_OK;
 }
 
-// The status stays OKRT_OK; the text is there for a host that logs okrt_last_error after its first frame.
+// The status stays OKRT_OK; the text is there for a host that logs okrt_last_error after its first frame: the default traversal
+// has chosen the (much slower) reference-order kernel for this scene, and why. Said once per upload of such an instance table,
+// and not at all to a host that has read okrt_get_build_info().flags or chose a traversal itself.
 static void warnShrunkInstancesOnce(okrt_ctx* c) {
-    if (!c->shrunkWarningDue) return;
+    if (!c->shrunkWarningDue || c->traversal != OKRT_TRAVERSAL_AUTO) return;
     c->shrunkWarningDue = false;
     if (c->buildFlagsRead) return;
     c->err = "warning: an instance matrix shrinks its mesh (OKRT_BUILD_FLAG_SHRUNK_INSTANCES): the reference drops geometry there (its BVH cull "
-             "compares a local-space box distance with the world-space best hit, RaytracerCS.hlsl:285 vs :311-318); OKRT_TRAVERSAL_FAST renders the true "
-             "closest hit instead. Select OKRT_TRAVERSAL_REFERENCE to reproduce the reference's picture exactly.";
+             "compares a local-space box distance with the world-space best hit, RaytracerCS.hlsl:285 vs :311-318). The default traversal "
+             "(OKRT_TRAVERSAL_AUTO) therefore renders this scene with the reference-order kernel, which reproduces the reference's picture "
+             "exactly but is many times slower than the fast pipeline. Select OKRT_TRAVERSAL_FAST for the true world-space closest hit at full speed.";
 }
 
 okrt_status okrt_commit(okrt_ctx* c) {
@@ -752,7 +778,9 @@ okrt_status okrt_get_build_info(okrt_ctx* c, okrt_build_info* out) {
     out->max_depth = bi.maxDepth;
     out->device_ms = bi.deviceMs;
     out->wall_ms = bi.wallMs;
-    out->flags = instanceFlags(c) | (c->materialsDark ? OKRT_BUILD_FLAG_DARK_MATERIALS : 0u);
+    FastCameraProbe probe;
+    fastCameraProbe(c->fast, &probe);
+    out->flags = c->instFlags | (c->materialsDark ? OKRT_BUILD_FLAG_DARK_MATERIALS : 0u) | (c->fast && !probe.chosePacket ? OKRT_BUILD_FLAG_CAMERA_PER_RAY : 0u);
     c->buildFlagsRead = true;
     return OKRT_OK;
 }
@@ -778,12 +806,12 @@ static okrt_status renderImpl(okrt_ctx* c, const okrt_render_data* rd, uint32_t 
 
     SceneView view = makeView(c, rd);
     unsigned long long* counters = c->countersOn ? (unsigned long long*)c->counters.ptr : nullptr;
-    const bool referenceOrder = c->traversal == OKRT_TRAVERSAL_REFERENCE || rd->debugMode != 0;
+    const bool referenceOrder = effectiveTraversal(c) == OKRT_TRAVERSAL_REFERENCE || rd->debugMode != 0;
     if (!referenceOrder) {
         okrt_status fs = ensureFast(c);
         if (fs != OKRT_OK) return fs;
-        warnShrunkInstancesOnce(c);
     }
+    warnShrunkInstancesOnce(c);
     // OKRT_OPT_TIMING: the launch set records into the ring's next slot; the slot is only claimed (ringNext / ringCount
     // advance) once the launches succeeded, so a refused or failed attempt leaves the ring as it was
     okrt_ctx::TimedFrame* tf = nullptr;
@@ -976,7 +1004,8 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
     OKRT_FLUSH(c);
     switch (opt) {
         case OKRT_OPT_TRAVERSAL:
-            if (value != OKRT_TRAVERSAL_REFERENCE && value != OKRT_TRAVERSAL_FAST) return fail(c, OKRT_ERR_INVALID_ARG, "traversal: 0 or 1");
+            if (value != OKRT_TRAVERSAL_REFERENCE && value != OKRT_TRAVERSAL_FAST && value != OKRT_TRAVERSAL_AUTO)
+                return fail(c, OKRT_ERR_INVALID_ARG, "traversal: 0 (reference order), 1 (fast) or 2 (auto)");
             c->traversal = (int)value;
             return OKRT_OK;
         case OKRT_OPT_MAX_BOUNCES:
@@ -993,13 +1022,18 @@ okrt_status okrt_set_option(okrt_ctx* c, okrt_option opt, int64_t value) {
         case OKRT_OPT_QUEUE_MEMORY_MB:
             if (value < 0) return fail(c, OKRT_ERR_INVALID_ARG, "queue memory: MiB >= 0");
             fastSetQueueBudget(&c->fast, (size_t)value << 20);
+            c->queueBudgetChosen = true;
             c->batchLimit = kMaxFramesPerLaunch;  // probe again from the top
             c->deferReserved = false;
             return OKRT_OK;
         case OKRT_OPT_PIPELINE:
             if (value < 0 || value > (int64_t)kPipelineMaxFrames) return fail(c, OKRT_ERR_INVALID_ARG, "pipeline: 0 (off) .. 32 frames per launch set");
-            c->pipelineOn = value != 0 && c->side[1] != nullptr;
+            c->pipelineOn = value != 0;
+            for (uint32_t k = 1; k < kPipelineSlots; ++k) c->pipelineOn = c->pipelineOn && c->side[k] != nullptr;  // (as okrt_create decides it)
+            for (uint32_t k = 0; k < kPipelineSlots; ++k) c->pipelineOn = c->pipelineOn && c->accumDone[k] != nullptr;
+            c->pipelineOn = c->pipelineOn && c->evJoinA && c->evJoinB;
             if (value) c->pipelineMaxFrames = (uint32_t)value;
+            c->deferReserved = false;  // (the reservation follows the launch shape: which slots a deferred set will ride)
             return OKRT_OK;
         case OKRT_OPT_LAST_SEGMENT_SHORTCUT: c->lastSegmentShortcut = value != 0; return OKRT_OK;
         case OKRT_OPT_LAST_SEGMENT_ANY_HIT: c->lastSegmentAnyHit = value != 0; return OKRT_OK;

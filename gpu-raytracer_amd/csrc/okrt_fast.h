@@ -105,13 +105,19 @@ struct FastDeviceResult {
 struct TopNode { float mn[3]; uint32_t left; float mx[3]; uint32_t right; uint32_t count; };
 uint32_t buildTopSAH(const float* boxes6, const uint32_t* weights, uint32_t n, std::vector<TopNode>& out);
 
+struct FastScene;  // device-resident structure + the wavefront queues
 struct DeviceBuilder;
 DeviceBuilder* deviceBuilderCreate();
 void deviceBuilderDestroy(DeviceBuilder*);
 bool buildFastDevice(DeviceBuilder& b, const FastInputs& in, const FastDeviceTables& dev, hipStream_t stream, FastDeviceResult& out, std::string& err);
 
-struct FastScene;  // device-resident structure + the wavefront queues
 
+// what the camera-segment probe of the first launch set after a build counted and chose (okrt_fast_pipeline.hip: probeCameraSegment)
+struct FastCameraProbe {
+    uint32_t tiles, chosePacket;
+    float packetNodeStepsPerTile, packetTriTestsPerTile, rayNodeVisitsPerRay, rayTriTestsPerRay, packetCost, perRayCost;
+};
+void fastCameraProbe(const FastScene* scene, FastCameraProbe* out);
 struct FastBuildInfo { uint32_t builder, numNodes, numTris, maxDepth; float deviceMs, wallMs; };
 // builder: 0 = host binned SAH (okrt_fast_build.cpp), 1 = device PLOC (okrt_fast_build_device.hip)
 bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& dev, uint32_t builder, hipStream_t stream, std::string& err);

@@ -33,6 +33,7 @@
 // this file owns the device-resident state and the launch sequence.
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -105,6 +106,9 @@ struct FastScene {
     } slot[kPipelineSlots];
     uint32_t overflowCap = 0;  // entries per thread the spill slabs need for the current tree
     int traceBlocks = 0, cus = 0;
+    // which algorithm traces the camera segment: decided once per structure from a probe of the first frame (probeCameraSegment)
+    int cameraPacket = -1;      // -1 = not decided yet, 1 = one wave walks the tree for its 8x8 tile, 0 = per-ray kernel
+    FastCameraProbe probe = {};
     size_t queueBudgetBytes = 0;  // OKRT_OPT_QUEUE_MEMORY_MB (0 = no limit)
 };
 
@@ -152,6 +156,8 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     fs.cus = cus;
     fs.traceBlocks = cus * (getenv("OKRT_FAST_BLOCKS_PER_CU") ? atoi(getenv("OKRT_FAST_BLOCKS_PER_CU")) : OKRT_TRACE_WAVES);
+    fs.cameraPacket = -1;
+    fs.probe = {};
     uint32_t need = 3 * fs.maxDepth + 4;
     fs.overflowCap = need > (uint32_t)kLdsStack ? need - kLdsStack : 1;  // (the slabs themselves are made by the launch set that needs them)
     return true;
@@ -264,6 +270,102 @@ void fastDestroy(FastScene* fs) {
     delete fs;
 }
 
+// ---- camera segment: packet or per-ray, per scene ------------------------------------------------------------------------
+// The packet kernel walks the UNION of its 64 rays' nodes and leaves once per wave; the per-ray kernel walks every ray's own
+// path at 40-60 % lane utilisation and pays the generate / hit-record / shade round trip through HBM. Which is cheaper depends
+// on the scene (r05 table, profiles/r05_packet_vs_per_ray.txt: the packet wins 1.5x on the Sponza-class scene, loses 1.9x on
+// 8 M sub-pixel triangles, where a tile's union is 105 triangle tests against 5 per ray). So the first launch set after a build
+// PROBES: about eight 8-row stripes spread over the FULL frame (not the context's own tile: every rank of a split decides alike,
+// and like a single-GPU context) are traced by the counting variants of both kernels, and a cost model in VALU wave-instructions
+// per tile — the unit both kernels are bound by (roofline.kernels[].valu_issue_frac) — picks one:
+//     packet   = 130 per node step + 95 per triangle test                        (counted per wave)
+//     per ray  = (125 per node visit + 95 per triangle test) / 0.5 lanes + 1500  (counted per lane; 1500 = the unfused segment's
+//                generate, hit-record and separate shading traffic, from the same table)
+// The per-ray kernel is taken when its cost is below 0.8 of the packet's (model / measured per-ray : packet ratios on the five
+// workloads: 0.35 / 0.52, 0.98 / 1.13, 2.1 / 1.7, 3.9 / 1.5, 1.7 / 1.5). The counts are deterministic, so the choice is; OKRT_FAST_PACKET=0/1 in the environment overrides it. Closest hits agree bit
+// for bit between the two (same arithmetic per lane); only equal-distance ties may pick another triangle.
+namespace {
+bool cameraUsesPacket(const FastScene& fs) {
+    static const int envPacket = getenv("OKRT_FAST_PACKET") ? atoi(getenv("OKRT_FAST_PACKET")) : -1;
+    if (3 * fs.maxDepth + 4 > (uint32_t)kPacketStack) return false;
+    if (envPacket >= 0) return envPacket != 0;
+    return fs.cameraPacket != 0;  // (undecided = packet: what a launch set without a probe uses)
+}
+
+bool probeCameraSegment(FastScene& fs, const SceneView& s, const okrt_render_data& rd, hipStream_t stream, std::string& err) {
+    fs.cameraPacket = 1;
+    fs.probe = {};
+    if (3 * fs.maxDepth + 4 > (uint32_t)kPacketStack || !fs.numTris) return true;  // (nothing to choose / nothing to trace)
+    const uint32_t W = rd.textureDims[0], H = rd.textureDims[1];
+    if (!W || !H) return true;
+    const uint32_t stripes = (H + 7) / 8, stride = std::max(1u, stripes / 8u);
+    TileView pt{W, H, 0, 8, stride / 2, stride};
+    for (uint32_t k = pt.stripeIndex; k * 8 < H; k += stride) pt.rows += std::min(8u, H - k * 8);
+    if (!pt.rows) return true;
+    const uint32_t perFrame = (((W + 7) >> 3) * ((pt.rows + 7) >> 3)) << 6;
+    const uint32_t cap = (((perFrame + kShards - 1) / kShards + 255) / 256) * 256;
+    const size_t items = (size_t)cap * kShards;
+    RayQueue q{};
+    HitBuffer hb{};
+    uint32_t* counts = nullptr;
+    uint2* overflow = nullptr;
+    unsigned long long* ctr = nullptr;  // two okrt_counters-shaped blocks: packet, per ray
+    auto release = [&]() {
+        for (void* p : {(void*)q.a, (void*)q.b, (void*)hb.h, (void*)hb.tri, (void*)counts, (void*)overflow, (void*)ctr})
+            if (p) hipFree(p);
+    };
+    const uint32_t countWords = 2 * kShards * kCursorStride;
+    bool ok = devAlloc(&q.a, items, err) && devAlloc(&q.b, items, err) && devAlloc(&hb.h, items, err) && devAlloc(&hb.tri, items, err) &&
+              devAlloc(&counts, countWords, err) && devAlloc(&overflow, (size_t)fs.traceBlocks * kTraceThreads * fs.overflowCap, err) &&
+              devAlloc(&ctr, 2 * kNumCounters, err);
+    unsigned long long host[2 * kNumCounters] = {};
+    hipError_t e = hipSuccess;
+    if (ok) {
+        e = hipMemsetAsync(ctr, 0, sizeof(host), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(counts, 0, countWords * sizeof(uint32_t), stream);
+    }
+    if (ok && e == hipSuccess) {
+        okrt_render_data prd = rd;
+        const FastView fv{fs.nodes.p, fs.tris.p, overflow, fs.overflowCap, (uint32_t)(fs.numNodes * sizeof(Node4Q)), (uint32_t)(fs.numTris * sizeof(Tri48))};
+        const ShardView sv{cap, perFrame, kBatch, 1u, nullptr, counts + kShards * kCursorStride};
+        launchGenerate(dim3((unsigned)(items / 256)), stream, prd, pt, q, perFrame, 1u);
+        launchPacket(true, false, dim3((unsigned)(fs.cus * 6)), stream, fs.nodes.p, fs.tris.p, s, prd, pt, q, hb, sv, 1u, ctr, ctr, FusedArgs{});
+        e = hipMemsetAsync(counts, 0, countWords * sizeof(uint32_t), stream);  // the cursors again, for the second walk over the same rays
+        launchTrace(true, 0, dim3(fs.traceBlocks), stream, fv, s, prd, pt, q, hb, sv, 1u, ctr + kNumCounters, ctr + kNumCounters);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(host, ctr, sizeof(host), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    release();
+    if (!ok) return false;
+    if (e != hipSuccess) {
+        err = std::string("camera-segment probe: ") + hipGetErrorString(e);
+        return false;
+    }
+    const double tiles = perFrame / 64.0, rays = (double)pt.rows * W;
+    FastCameraProbe& pr = fs.probe;
+    pr.tiles = perFrame / 64;
+    pr.packetNodeStepsPerTile = (float)(host[10] / 64.0 / tiles);
+    pr.packetTriTestsPerTile = (float)(host[11] / 64.0 / tiles);
+    pr.rayNodeVisitsPerRay = (float)(host[kNumCounters + 10] / rays);
+    pr.rayTriTestsPerRay = (float)(host[kNumCounters + 11] / rays);
+    pr.packetCost = 130.f * pr.packetNodeStepsPerTile + 95.f * pr.packetTriTestsPerTile;
+    pr.perRayCost = (125.f * pr.rayNodeVisitsPerRay + 95.f * pr.rayTriTestsPerRay) / 0.5f + 1500.f;
+    fs.cameraPacket = pr.perRayCost < 0.8f * pr.packetCost ? 0 : 1;  // (a margin: on the 871 k-triangle scene the model says 0.98, the clock 1.13)
+    pr.chosePacket = (uint32_t)fs.cameraPacket;
+    if (getenv("OKRT_FAST_PROBE_PRINT"))  // developer knob: the numbers behind the choice
+        fprintf(stderr, "[okrt] camera-segment probe: %u tiles; packet %.2f node steps + %.2f triangle tests per tile = %.0f; per ray %.2f node visits + %.2f "
+                        "triangle tests = %.0f -> %s\n", pr.tiles, pr.packetNodeStepsPerTile, pr.packetTriTestsPerTile, pr.packetCost, pr.rayNodeVisitsPerRay,
+                pr.rayTriTestsPerRay, pr.perRayCost, fs.cameraPacket ? "packet" : "per ray");
+    return true;
+}
+}  // namespace
+
+void fastCameraProbe(const FastScene* fs, FastCameraProbe* out) {
+    if (fs) *out = fs->probe, out->chosePacket = cameraUsesPacket(*fs) ? 1u : 0u;
+    else std::memset(out, 0, sizeof(*out));
+}
+
 // Everything a launch set of `frames` frames needs in device memory, on queue slot `slot`: ray queues, hit records, radiance
 // slots, counters, spill slab, RenderData copy. Called by launchFast, and ahead of time by fastReserve so that a deferred
 // okrt_render learns about an allocator refusal when it is issued, not when its frames are finally launched.
@@ -289,9 +391,8 @@ LaunchStatus ensureQueues(FastScene& fs, FastScene::LaunchSlot& ls, const SceneV
     // the unfused camera segment (generate -> trace -> shade) or a third segment (queues ping-pong from b = 2 on); with
     // the fused camera kernel and NUM_BOUNCES = 1 — the reference's configuration — it is never allocated: 76 instead of
     // 132 bytes per ray and frame in flight. Per pixel and frame of a multi-frame set: a 16-byte radiance slot.
-    static const bool envPacket0 = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused0 = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
-    const bool needQ0 = !(envPacket0 && envFused0 && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack) || s.maxBounces >= 2;
+    const bool needQ0 = !(cameraUsesPacket(fs) && envFused0) || s.maxBounces >= 2;
     const size_t needBytes = items * (needQ0 ? 2 * 56 + 20 : 56 + 20) + (frames > 1 || frameSlots ? (size_t)t.rows * t.W * frames * 16 : 0);
     if (fs.queueBudgetBytes && needBytes > fs.queueBudgetBytes && frames > 1) {
         err = "launch set exceeds the queue memory budget";
@@ -355,6 +456,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
                         unsigned long long* counters, unsigned long long* rayTotals, hipStream_t stream, hipEvent_t* events, uint32_t frames,
                         const LaunchOrder& order, std::string& err) {
     FastScene::LaunchSlot& ls = fs.slot[order.slot % kPipelineSlots];
+    if (fs.cameraPacket < 0 && !probeCameraSegment(fs, s, rd, stream, err)) return LaunchStatus::OutOfMemory;
     QueuePlan qp;
     const LaunchStatus qs = ensureQueues(fs, ls, s, t, frames, order.frameSlots, stream, qp, err);
     if (qs != LaunchStatus::Ok) return qs;
@@ -386,9 +488,8 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
                          ls.counts + kCursorBase + b * kShards * kCursorStride};
     };
     mark();
-    static const bool envPacket = !getenv("OKRT_FAST_PACKET") || atoi(getenv("OKRT_FAST_PACKET")) != 0;
     static const bool envFused = !getenv("OKRT_FAST_FUSED") || atoi(getenv("OKRT_FAST_FUSED")) != 0;
-    const bool packet = envPacket && 3 * fs.maxDepth + 4 <= (uint32_t)kPacketStack;  // camera rays: one wave walks the tree for its tile
+    const bool packet = cameraUsesPacket(fs);  // camera rays: one wave walks the tree for its tile
     static const int envPacketBlocks = getenv("OKRT_FAST_PACKET_BLOCKS") ? atoi(getenv("OKRT_FAST_PACKET_BLOCKS")) : 6;
     const dim3 pg((unsigned)(fs.cus * envPacketBlocks));  // (2 KB LDS: more blocks per CU fit, but the sweep is flat from 6 to 16)
     // the launch set's RenderData in device memory, written by a kernel from its by-value argument: stream-ordered after

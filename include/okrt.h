@@ -115,14 +115,16 @@ typedef enum okrt_option {
     /* 0 = reference-order traversal over the uploaded octree -> mesh -> BVH tables
      *     (RaytracerCS.hlsl:256-334, bit-identical visit order; produces the reference's
      *     bbCheckCount / triCheckCount);
-     * 1 = (default) the MI355X traversal structure derived from the same tables at commit: instances are baked to
-     *     world space, so it returns the world-space closest hit. For rigid instances (every benchmark scene; identity
-     *     instances bit for bit) that IS the reference's result up to equal-distance ties. Under Transform.scale != 1
-     *     the reference culls per-mesh BVH boxes by a local-space distance against the world-space best hit (quirk Q3,
-     *     RaytracerCS.hlsl:273-287 vs :311-318): conservative — same picture — when every scale factor is >= 1, but
-     *     with a factor < 1 the reference skips boxes that hold the closest hit. Mode 1 does not reproduce those
-     *     drop-outs (tests/test_gpu_fullsize.py::test_scaled_instances_*); mode 0 does, exactly. okrt_get_build_info
-     *     reports OKRT_BUILD_FLAG_SHRUNK_INSTANCES so a host that needs the reference's artefacts can select mode 0. */
+     * 1 = the MI355X traversal structure derived from the same tables at commit: instances are baked to world space, so it
+     *     returns the world-space closest hit. For rigid instances (every benchmark scene; identity instances bit for bit)
+     *     that IS the reference's result up to equal-distance ties. Under Transform.scale != 1 the reference culls per-mesh
+     *     BVH boxes by a local-space distance against the world-space best hit (quirk Q3, RaytracerCS.hlsl:273-287 vs
+     *     :311-318): conservative — same picture — when every scale factor is >= 1, but with a factor < 1 the reference
+     *     skips boxes that hold the closest hit. Mode 1 does not reproduce those drop-outs
+     *     (tests/test_gpu_fullsize.py::test_scaled_instances_*); mode 0 does, exactly;
+     * 2 = (default, OKRT_TRAVERSAL_AUTO) parity first: mode 1 wherever it shows the reference's picture, mode 0 for a scene
+     *     whose instance table has OKRT_BUILD_FLAG_SHRUNK_INSTANCES (okrt_get_build_info) — many times slower there, and
+     *     said once through okrt_last_error. A host that prefers the true closest hit at full speed selects mode 1. */
     OKRT_OPT_TRAVERSAL = 0,
     /* NUM_BOUNCES of RaytracerCS.hlsl:6 (default 1 = HEAD; a path has max_bounces+1 segments). */
     OKRT_OPT_MAX_BOUNCES = 1,
@@ -154,9 +156,11 @@ typedef enum okrt_option {
      * 3840x2160 -> 0.76 GB per frame. OKRT_OPT_QUEUE_MEMORY_MB bounds it. */
     OKRT_OPT_DEFER = 5,
     /* Upper bound, in MiB, for the ray queues of one launch set (76 or 132 bytes per ray and frame in flight + 16 per
-     * pixel and frame, see OKRT_OPT_DEFER; 1080p x 64 frames = 12 GiB). 0 (default) = whatever hipMalloc grants. A launch set that
-     * does not fit — by this bound or by the allocator — is split in halves until it does; a single frame is
-     * always attempted. */
+     * pixel and frame, see OKRT_OPT_DEFER; 1080p x 64 frames = 12 GiB). Default, when the host never sets it: a quarter of the
+     * device memory that is free at okrt_resize (72 GB on an otherwise empty 288 GB part: 64-frame sets at 3840x2160 still
+     * fit; on a crowded device the sets shrink instead of starving the host's other allocations). 0 = no bound but the
+     * allocator's. A launch set that does not fit — by this bound or by the allocator — is split in halves until it does; a
+     * single frame is always attempted. */
     OKRT_OPT_QUEUE_MEMORY_MB = 6,
     /* Test hook: n > 0 = the n-th ray-queue allocation from now on fails as hipMalloc would when memory runs out (so that
      * the launch-set split on a REAL allocator failure can be tested); 0 = off. Process-wide. */
@@ -175,8 +179,9 @@ typedef enum okrt_option {
      * Small tiles (round 4): a LARGER launch set that traces at most 12 Mi camera rays — one rank's stripes of an N-way split —
      * is issued as two sub-sets that ride the slots the same way (8-way split of a 1080p frame, 20 frames: 1.67 -> 1.58 ms per
      * rank; a full 1080p frame, where it would cost 4.5 %, is not cut). Same framebuffers bit for bit.
-     * Footprint: the queues of up to FOUR launch sets of up to n frames (default: 4 x 0.76 GB at 1080p). 0 = one launch
-     * set at a time. */
+     * Footprint: the queues of up to FOUR launch sets in flight: sets of up to n frames (default: 4 x 0.76 GB at 1080p), and
+     * the sub-sets of a small tile's larger set, each up to 32 frames on its own slot (a 64-frame set of a 1/8 tile keeps
+     * about twice the queue memory of one undivided set). 0 = one launch set at a time. */
     OKRT_OPT_PIPELINE = 8,
     /* 1 (default) = work whose result is provably +-0 is not executed on the LAST path segment. When the frame's RenderData
      * holds no light (RaytracerCS.hlsl:448-487 never runs), every uploaded Material (t6, t7) has emission colour * power ==
@@ -199,6 +204,7 @@ typedef enum okrt_option {
 
 #define OKRT_TRAVERSAL_REFERENCE 0
 #define OKRT_TRAVERSAL_FAST 1
+#define OKRT_TRAVERSAL_AUTO 2
 
 /* Sums over all rendered pixels since the last okrt_reset_counters. The first five are defined
  * by the reference traversal order (they are what the reference's debug heat maps count,
@@ -226,9 +232,9 @@ okrt_status okrt_device_count(int* out_count);
 okrt_status okrt_create(int device, okrt_ctx** out_ctx);
 okrt_status okrt_destroy(okrt_ctx* ctx);
 /* never NULL; "" when nothing was reported; ctx == NULL: why the last okrt_create failed. Besides the message of the last
- * failed call it carries ONE kind of warning with status OKRT_OK (text starts with "warning:"): the first fast-traversal
- * render after a build whose instance table has OKRT_BUILD_FLAG_SHRUNK_INSTANCES, unless the host has called
- * okrt_get_build_info (see OKRT_OPT_TRAVERSAL) — the one place where the default picture knowingly differs from the reference's. */
+ * failed call it carries ONE kind of warning with status OKRT_OK (text starts with "warning:"): the first render under
+ * OKRT_TRAVERSAL_AUTO of an instance table with OKRT_BUILD_FLAG_SHRUNK_INSTANCES — the default then renders with the slow
+ * reference-order kernel to keep the reference's picture (see OKRT_OPT_TRAVERSAL) — unless the host has called okrt_get_build_info. */
 const char* okrt_last_error(const okrt_ctx* ctx);
 
 /* ---- scene upload (the Scene->Graphics interface) ------------------------------------------ */
@@ -343,11 +349,17 @@ typedef struct okrt_build_info {
 #define OKRT_BUILD_FLAG_SCALED_INSTANCES 1u
 /* some instance matrix shrinks at least one direction (a singular value < 1): there the reference's BVH cull compares a
  * LARGER local-space box distance with the world-space best hit (quirk Q3, RaytracerCS.hlsl:285 vs :311-318) and drops
- * geometry it should test; OKRT_TRAVERSAL_FAST returns the true closest hit instead (documented deviation) */
+ * geometry it should test; OKRT_TRAVERSAL_FAST returns the true closest hit instead (documented deviation), the default
+ * OKRT_TRAVERSAL_AUTO renders such a scene in reference order */
 #define OKRT_BUILD_FLAG_SHRUNK_INSTANCES 2u
 /* every uploaded Material (t6, t7) has emission colour * power == (0, 0, 0) and |albedo| <= 1: the material half of the condition
  * under which OKRT_OPT_LAST_SEGMENT_SHORTCUT applies (the other half is a RenderData without lights) */
 #define OKRT_BUILD_FLAG_DARK_MATERIALS 4u
+/* the camera segment of this structure is traced ray by ray instead of one 8x8 pixel packet per wave: chosen by the first launch
+ * set after a build from a probe of that frame (about eight stripes of the full frame through the counting variants of both
+ * kernels; gpu-raytracer_amd/csrc/okrt_fast_pipeline.hip: probeCameraSegment) — scenes of sub-pixel triangles, where a packet
+ * walks the union of 64 rays' leaves. Meaningful after the first fast-traversal render. Same closest hits either way. */
+#define OKRT_BUILD_FLAG_CAMERA_PER_RAY 8u
 okrt_status okrt_get_build_info(okrt_ctx* ctx, okrt_build_info* out);
 /* Test / tooling access: copies the derived structure to the host (64 B per node, 48 B per triangle; layouts in
  * gpu-raytracer_amd/csrc/okrt_fast.h). Either pointer may be NULL. OKRT_ERR_STATE if nothing is built. */

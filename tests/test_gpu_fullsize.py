@@ -487,16 +487,17 @@ def test_obj_import_renders_like_the_oracle(oracle, tmp_path):
 
 
 def test_shrunk_instances_are_announced_once_unless_the_host_read_the_flag():
-    """The one place where the DEFAULT picture knowingly differs from the reference's (quirk Q3) must not be silent: the
-    first fast-traversal render after a build with OKRT_BUILD_FLAG_SHRUNK_INSTANCES returns OKRT_OK and leaves a
-    "warning:" text in okrt_last_error — once, and not at all for a host that looked at okrt_get_build_info().flags."""
+    """Under the default traversal (OKRT_TRAVERSAL_AUTO) a scene with a shrunk instance is rendered by the slow reference-order
+    kernel to keep the reference's picture (quirk Q3). That choice must not be silent: the first such render returns OKRT_OK and
+    leaves a "warning:" text in okrt_last_error — once, and not at all for a host that looked at okrt_get_build_info().flags or
+    chose a traversal itself."""
     kw = dict(seed=21, n_objects=6, detail=8, transforms=True, octree=(0, 50))
     shrunk = scenes.small_mesh_scene(scales=SCALES["down"], **kw)
     grown = scenes.small_mesh_scene(scales=SCALES["up"], **kw)
     last = lambda rt: rt.ctx.fns.last_error(rt.ctx.h).decode()  # noqa: E731
     rt, _, _ = scenes.instantiate(shrunk, 64, 36)
     rt.render()  # status OK (the binding raises otherwise)
-    assert last(rt).startswith("warning:") and "OKRT_TRAVERSAL_REFERENCE" in last(rt)
+    assert last(rt).startswith("warning:") and "OKRT_TRAVERSAL_FAST" in last(rt) and "reference-order" in last(rt)
     assert rt.ctx.fns.set_option(rt.ctx.h, abi.OPT_MAX_BOUNCES, 77) == -1  # a real error replaces the text ...
     err = last(rt)
     assert err and not err.startswith("warning:")
@@ -513,8 +514,42 @@ def test_shrunk_instances_are_announced_once_unless_the_host_read_the_flag():
     rt.render(); rt.ctx.read_accum()
     assert last(rt) == ""
     rt.close()
-    rt, _, _ = scenes.instantiate(shrunk, 64, 36)  # the reference-order traversal reproduces the artefact: nothing to say either
-    rt.ctx.set_option(abi.OPT_TRAVERSAL, abi.TRAVERSAL_REFERENCE)
-    rt.render(); rt.ctx.read_accum()
-    assert last(rt) == ""
-    rt.close()
+    for chosen in (abi.TRAVERSAL_REFERENCE, abi.TRAVERSAL_FAST):  # a host that chose a traversal itself: nothing to say either
+        rt, _, _ = scenes.instantiate(shrunk, 64, 36)
+        rt.ctx.set_option(abi.OPT_TRAVERSAL, chosen)
+        rt.render(); rt.ctx.read_accum()
+        assert last(rt) == ""
+        rt.close()
+
+
+def test_shrunk_instances_default_traversal_shows_the_references_picture(oracle):
+    """Parity is the default (OKRT_TRAVERSAL_AUTO): with a scale factor < 1 in the instance table the untouched context renders
+    what the reference renders — SURVEY 8c's 1-spp rule against the oracle, counters included — both per call and through
+    okrt_render_frames; scenes whose scale factors are all >= 1 stay on the fast pipeline (and still meet the rule: the
+    reference's cull is conservative there)."""
+    W, H = 256, 144
+    for kind in ("down", "nonuniform", "up"):
+        desc = scenes.small_mesh_scene(seed=21, n_objects=6, detail=12, transforms=True, with_lights=True, octree=(0, 50), scales=SCALES[kind])
+        rt, _, _ = scenes.instantiate(desc, W, H)  # no OKRT_OPT_TRAVERSAL: the default
+        rt.ctx.set_option(abi.OPT_COUNTERS, 1)
+        rt.render()
+        ga, gc = rt.ctx.read_accum(), rt.ctx.counters()
+        ca, cc = oracle_rows(oracle, desc, W, H, 1)
+        frac, rmse, nanmm, _ = compare_accum(ga, ca)
+        shrunk = bool(rt.ctx.build_info()["flags"] & abi.BUILD_FLAG_SHRUNK_INSTANCES)
+        assert shrunk == (kind != "up")
+        if shrunk:  # the reference-order kernel ran: the reference's own check counters equal the oracle's
+            assert frac >= 0.995 and rmse <= 0.02, (kind, frac, rmse)
+            for key in ("n_oct", "n_mesh", "n_node", "n_tri", "segments"):
+                assert abs(gc[key] - cc[key]) <= 0.003 * max(cc[key], 1) + 8, (kind, key, gc[key], cc[key])
+            rt.ctx.set_option(abi.OPT_COUNTERS, 0)
+            rt.resetAccumulation()
+            rt.renderFrames(3)  # batched calls take the same decision
+            g3 = rt.ctx.read_accum()
+            c3, _ = oracle_rows(oracle, desc, W, H, 1, frames=3)
+            f3, r3, _, _ = compare_accum(g3, c3, frames=3)
+            assert f3 >= 0.995 and r3 <= 0.02 and (g3[..., 3] == 3).all(), (kind, f3, r3)
+        else:
+            assert gc["n_node"] == 0 and gc["fast_nodes"] > 0  # the fast pipeline ran
+            assert_outliers_are_explained(desc, ga, ca, W, H)
+        rt.close()

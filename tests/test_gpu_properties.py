@@ -323,6 +323,32 @@ def test_launch_sets_shrink_to_the_queue_memory_budget():
     rt.close()
 
 
+def test_the_default_queue_budget_is_a_quarter_of_the_free_memory(monkeypatch):
+    """okrt.h, OKRT_OPT_QUEUE_MEMORY_MB: a host that never sets the bound gets a quarter of the device memory free at okrt_resize
+    (OKRT_QUEUE_MEMORY_ASSUME_FREE_MB stands in for hipMemGetInfo here: 96 MiB "free" -> 24 MiB, the case of the test above);
+    an explicit 0 lifts it again. Framebuffers do not change either way."""
+    desc = scenes.small_mesh_scene(seed=4, n_objects=5, detail=10, with_lights=True)
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.renderFrames(48)
+    want = rt.ctx.read_accum().copy()
+    rt.close()
+    monkeypatch.setenv("OKRT_QUEUE_MEMORY_ASSUME_FREE_MB", "96")
+    rt, sc, res = scenes.instantiate(desc, 320, 180)
+    rt.ctx.set_option(abi.OPT_TIMING, 64)
+    rt.renderFrames(48)
+    assert np.array_equal(rt.ctx.read_accum(), want, equal_nan=True)
+    _, launches, frames = rt.ctx.interval_ms()
+    assert frames // launches <= 3, (launches, frames)  # 7.8 MiB per frame in flight under a 24 MiB bound
+    rt.ctx.set_option(abi.OPT_QUEUE_MEMORY_MB, 0)
+    rt.ctx.set_option(abi.OPT_TIMING, 64)
+    rt.resetAccumulation()
+    rt.renderFrames(48)
+    assert np.array_equal(rt.ctx.read_accum(), want, equal_nan=True)
+    _, launches, frames = rt.ctx.interval_ms()
+    assert launches <= 2 and frames == 48, (launches, frames)  # one set (issued as two sub-sets on the pipeline slots: a small tile)
+    rt.close()
+
+
 def test_launch_sets_shrink_when_the_allocator_says_no():
     """The same split on a REAL allocator failure (okrt.h, OKRT_OPT_QUEUE_MEMORY_MB: "by this bound or by the allocator"):
     OKRT_OPT_DEBUG_FAIL_ALLOC makes the n-th queue allocation report hipErrorOutOfMemory. The failed launch set is retried

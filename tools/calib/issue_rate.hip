@@ -8,6 +8,8 @@
 //   cvt        v_cvt_f32_ubyte0          (8-bit plane decode)
 //   salu       s_add_u32 / s_and_b32     (what the packet kernel's scalar sort and the per-iteration bookkeeping are made of)
 //   fma+salu   one of each per pair      (do the vector and the scalar port issue side by side?)
+//   cndm_vcc / cndm_sgpr  v_cndmask_b32 selecting by VCC / by an SGPR pair;  cmp_sgpr  v_cmp_*_f32 into an SGPR pair;
+//   cswap      the sort network's compare-and-swap (1 v_cmp + 4 v_cndmask);  minmax_u  v_min_u32 / v_max_u32 (packed-key swap)
 // Output: instructions per cycle per SIMD = N / (s_memtime delta of the wave that ran longest), and per quad-cycle (x4: the unit of the
 // SQ_* counters). build: hipcc --offload-arch=gfx950 -O3 -o tools/calib/issue_rate tools/calib/issue_rate.hip
 #include <hip/hip_runtime.h>
@@ -21,10 +23,12 @@
 constexpr int kUnroll = 64;  // instructions (or pairs) per loop trip
 
 template <int KIND>
-__global__ __launch_bounds__(256) void issueKernel(uint32_t trips, unsigned long long* cycles, float* sink) {
+__global__ __launch_bounds__(1024) void issueKernel(uint32_t trips, unsigned long long* cycles, float* sink) {
     float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float m = 1.0000001f, c = 1e-9f;
     uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    unsigned long long mask = 0x5555AAAA3333CCCCull ^ blockIdx.x, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    if (KIND == 1 || KIND == 10) asm volatile("s_mov_b64 vcc, %0" : : "s"(mask) : "vcc");
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (uint32_t t = 0; t < trips; ++t) {
 #pragma unroll
@@ -49,6 +53,30 @@ __global__ __launch_bounds__(256) void issueKernel(uint32_t trips, unsigned long
                 asm volatile("s_add_u32 %0, %0, 3\n s_and_b32 %1, %1, 0xffff\n s_add_u32 %2, %2, 5\n s_and_b32 %3, %3, 0xfff\n"
                              "s_add_u32 %0, %0, 7\n s_and_b32 %1, %1, 0xff\n s_add_u32 %2, %2, 9\n s_and_b32 %3, %3, 0xf"
                              : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+            } else if (KIND == 6) {  // select through an SGPR pair (what the compiler emits for `c ? a : b` with the condition of a v_cmp_..._e64)
+                asm volatile("v_cndmask_b32 %0, %0, %8, %9\n v_cndmask_b32 %1, %1, %8, %9\n v_cndmask_b32 %2, %2, %8, %9\n v_cndmask_b32 %3, %3, %8, %9\n"
+                             "v_cndmask_b32 %4, %4, %8, %9\n v_cndmask_b32 %5, %5, %8, %9\n v_cndmask_b32 %6, %6, %8, %9\n v_cndmask_b32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "s"(mask));
+            } else if (KIND == 7) {  // compare into an SGPR pair
+                asm volatile("v_cmp_lt_f32 %0, %4, %8\n v_cmp_lt_f32 %1, %5, %8\n v_cmp_lt_f32 %2, %6, %8\n v_cmp_lt_f32 %3, %7, %8\n"
+                             "v_cmp_gt_f32 %0, %4, %8\n v_cmp_gt_f32 %1, %5, %8\n v_cmp_gt_f32 %2, %6, %8\n v_cmp_gt_f32 %3, %7, %8"
+                             : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(m));
+            } else if (KIND == 8) {  // the compare-and-swap of the child sort: one compare, four selects on its result (x2 per block = 10 instructions)
+                asm volatile("v_cmp_lt_f32 %8, %1, %0\n v_cndmask_b32 %4, %0, %1, %8\n v_cndmask_b32 %5, %1, %0, %8\n v_cndmask_b32 %6, %2, %3, %8\n v_cndmask_b32 %7, %3, %2, %8\n"
+                             "v_cmp_lt_f32 %9, %5, %4\n v_cndmask_b32 %0, %4, %5, %9\n v_cndmask_b32 %1, %5, %4, %9\n v_cndmask_b32 %2, %6, %7, %9\n v_cndmask_b32 %3, %7, %6, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&s"(m0), "=&s"(m1));
+            } else if (KIND == 10) {  // VOP3 encoding of the VCC select
+                asm volatile("v_cndmask_b32_e64 %0, %0, %8, vcc\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc\n"
+                             "v_cndmask_b32_e64 %4, %4, %8, vcc\n v_cndmask_b32_e64 %5, %5, %8, vcc\n v_cndmask_b32_e64 %6, %6, %8, vcc\n v_cndmask_b32_e64 %7, %7, %8, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");
+            } else if (KIND == 11) {  // VCC select whose VCC comes from a v_cmp in the same block (the compiler's usual pairing), no self-dependence
+                asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %4, %1, %8, vcc\n v_cndmask_b32 %5, %2, %8, vcc\n v_cndmask_b32 %6, %3, %8, vcc\n"
+                             "v_cmp_gt_f32 vcc, %1, %8\n v_cndmask_b32 %7, %0, %8, vcc\n v_cndmask_b32 %4, %2, %8, vcc\n v_cndmask_b32 %5, %3, %8, vcc"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");
+            } else if (KIND == 9) {  // the same swap on packed keys: v_min_u32 / v_max_u32 (a key-value sort with the value in the key's low bits)
+                asm volatile("v_min_u32 %4, %0, %1\n v_max_u32 %5, %0, %1\n v_min_u32 %6, %2, %3\n v_max_u32 %7, %2, %3\n"
+                             "v_min_u32 %0, %4, %6\n v_max_u32 %1, %4, %6\n v_min_u32 %2, %5, %7\n v_max_u32 %3, %5, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
             } else {  // 5: fma + salu interleaved (8 of each per block = 16 instructions)
                 asm volatile("v_fma_f32 %0, %0, %12, %13\n s_add_u32 %8, %8, 3\n v_fma_f32 %1, %1, %12, %13\n s_and_b32 %9, %9, 0xffff\n"
                              "v_fma_f32 %2, %2, %12, %13\n s_add_u32 %10, %10, 5\n v_fma_f32 %3, %3, %12, %13\n s_and_b32 %11, %11, 0xfff\n"
@@ -60,36 +88,36 @@ __global__ __launch_bounds__(256) void issueKernel(uint32_t trips, unsigned long
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
-    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 ^ s1 ^ s2 ^ s3);
-    if (r == 1.2345e-30f) sink[blockIdx.x * 256 + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 ^ s1 ^ s2 ^ s3) + (float)(m0 ^ m1 ^ m2 ^ m3);
+    if (r == 1.2345e-30f) sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
 template <int KIND>
-static void measure(const char* name, int perPair, int cus, unsigned long long* dCycles, float* sink) {
+static void measure(const char* name, double perSlot, int cus, unsigned long long* dCycles, float* sink) {
     const uint32_t trips = 4000;
-    for (int wavesPerSimd : {1, 2, 4, 7, 8}) {
-        // one block = 4 waves = one wave per SIMD of the CU it lands on; W blocks per CU fill W waves per SIMD
-        const int blocks = cus * wavesPerSimd;
+    for (int wavesPerSimd : {1, 2, 4, 8}) {
+        // one block per CU (two of 1024 threads for 8 waves per SIMD): a block of 256 * w threads puts w waves on each SIMD of its CU
+        const int threads = 256 * (wavesPerSimd == 8 ? 4 : wavesPerSimd), blocks = cus * (wavesPerSimd == 8 ? 2 : 1);
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        issueKernel<KIND><<<blocks, 256>>>(trips, dCycles, sink);
+        issueKernel<KIND><<<blocks, threads>>>(trips, dCycles, sink);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        issueKernel<KIND><<<blocks, 256>>>(trips, dCycles, sink);
+        issueKernel<KIND><<<blocks, threads>>>(trips, dCycles, sink);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float ms = 0.f;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        std::vector<unsigned long long> cyc((size_t)blocks * 4);
+        std::vector<unsigned long long> cyc((size_t)blocks * (threads / 64));
         CK(hipMemcpy(cyc.data(), dCycles, cyc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long worst = 0;
         double mean = 0;
         for (auto c : cyc) { worst = c > worst ? c : worst; mean += (double)c; }
         mean /= (double)cyc.size();
-        // a SIMD ran wavesPerSimd waves (if the dispatcher spread the blocks evenly), each trips * kUnroll * perPair instructions
-        const double insts = (double)wavesPerSimd * trips * kUnroll * perPair;
-        printf("%-9s %5d %12.3f %14.0f %14.0f %12.3f %12.3f\n", name, wavesPerSimd, ms, mean, (double)worst, insts / mean, 4.0 * insts / mean);
+        // a SIMD ran wavesPerSimd waves side by side (mean ~ worst says the blocks were spread evenly), each trips * kUnroll * perSlot instructions
+        const double insts = (double)wavesPerSimd * trips * kUnroll * perSlot;
+        printf("%-10s %5d %12.3f %14.0f %14.0f %12.3f %12.3f\n", name, wavesPerSimd, ms, mean, (double)worst, insts / (double)worst, 4.0 * insts / (double)worst);
         CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }
 }
@@ -101,11 +129,18 @@ int main() {
     unsigned long long* dCycles;
     float* sink;
     CK(hipMalloc((void**)&dCycles, (size_t)cus * 8 * 4 * sizeof(unsigned long long)));
-    CK(hipMalloc((void**)&sink, (size_t)cus * 8 * 256 * sizeof(float)));
-    printf("# %d CUs; %d-instruction unrolled loop of independent instructions, 4000 trips, 256-thread blocks (one wave per SIMD each), W blocks per CU\n", cus, kUnroll);
-    printf("%-9s %5s %12s %14s %14s %12s %12s\n", "kind", "W", "kernel ms", "mean cyc/wave", "worst cyc/wave", "inst/cyc/SIMD", "inst/quad-cyc");
+    CK(hipMalloc((void**)&sink, (size_t)cus * 2 * 1024 * sizeof(float)));
+    printf("# %d CUs; unrolled loop of independent instructions, 4000 trips x %d slots; one block of 256*W threads per CU (W waves per SIMD; W = 8: two blocks of 1024)\n", cus, kUnroll);
+    printf("# rates = W * instructions per wave / the slowest wave's s_memtime span (shader clocks)\n");
+    printf("%-10s %5s %12s %14s %14s %12s %12s\n", "kind", "W", "kernel ms", "mean cyc/wave", "worst cyc/wave", "inst/cyc/SIMD", "inst/quad-cyc");
     measure<0>("fma", 1, cus, dCycles, sink);
-    measure<1>("cndmask", 1, cus, dCycles, sink);
+    measure<1>("cndm_vcc", 1, cus, dCycles, sink);
+    measure<10>("cndm_vcc64", 1, cus, dCycles, sink);
+    measure<11>("cmp+cndm_v", 1, cus, dCycles, sink);
+    measure<6>("cndm_sgpr", 1, cus, dCycles, sink);
+    measure<7>("cmp_sgpr", 1, cus, dCycles, sink);
+    measure<8>("cswap", 10.0 / 8.0, cus, dCycles, sink);
+    measure<9>("minmax_u", 1, cus, dCycles, sink);
     measure<2>("minmax", 1, cus, dCycles, sink);
     measure<3>("cvt", 1, cus, dCycles, sink);
     measure<4>("salu", 1, cus, dCycles, sink);
