@@ -414,7 +414,10 @@ def main():
     if world == 1 and os.environ.get("OKRT_BENCH_TILE"):  # developer knob: time one rank's share of an N-way split on 1 GPU
         sr, si, ss = (int(v) for v in os.environ["OKRT_BENCH_TILE"].split(","))
         ctx.set_tile(sr, si, ss)
-    group = mgpu.TileGroup(fns, plan, [st.ctx.h for st in ranks], store, frame=(W, H, STRIPE_ROWS), read_tile=lambda k: ranks[k].ctx.read_accum())
+    # the root of the exchanges: the rank that owns the fewest rows of the striped split (it finishes its own frames first); the
+    # samples split has no lighter rank
+    group = mgpu.TileGroup(fns, plan, [st.ctx.h for st in ranks], store, frame=(W, H, STRIPE_ROWS), read_tile=lambda k: ranks[k].ctx.read_accum(),
+                           root=0 if samples_split else None)
 
     def exchange(final=False):
         if world <= 1:
@@ -518,12 +521,16 @@ def main():
     enqueue_s[0], enqueue_s[1] = 0.0, 0
     sync(before_region=True)
     t0 = time.perf_counter()
-    ctx.timer_begin()
+    for st in ranks:
+        st.ctx.timer_begin()
     run_frames(steps_here, not samples_split)
-    ctx.timer_end()
+    for st in ranks:
+        st.ctx.timer_end()  # every rank's own span: its frames, without the final exchange
     exchange(final=True)
     sync()
     elapsed = time.perf_counter() - t0
+    rank_region = {st.rank: st.ctx.timer_elapsed_ms() for st in ranks}
+    gather_in_region = group.exchange_ms() if world > 1 else None  # root only: device time of the region's last exchange on the root's stream
     mem_gb = device_memory_in_use_gb(plan["devices"])  # queues of the timed launch sets are allocated now
     enqueue_ms_per_set = enqueue_s[0] * 1e3 / max(enqueue_s[1], 1)
     trace_ms, shade_ms, other_ms, timed_frames = ctx.stage_ms()
@@ -639,6 +646,13 @@ def main():
 
     def job_sum_dict(d):
         return mgpu.allreduce_json(store, d, lambda ds: {k: sum(x[k] for x in ds) for k in ds[0]})
+    if store:  # one process per rank: every rank's span and the root's exchange time travel through the store
+        merged = {}
+        for part in [json.loads(b.decode()) for b in store.allgather(json.dumps({str(k): v for k, v in rank_region.items()}).encode())]:
+            merged.update({int(k): v for k, v in part.items()})
+        rank_region = merged
+        gather_in_region = job_max(gather_in_region if gather_in_region is not None else -1.0)
+        gather_in_region = None if gather_in_region is None or gather_in_region < 0 else gather_in_region
     rays_total = job_sum(rays_local)
     elapsed_max = job_max(elapsed)
     repeat_ms = [job_max(v) for v in repeat_ms]
@@ -691,6 +705,14 @@ def main():
                        "tile_split": ("samples split: every rank renders the whole frame for its own block of frame indices" if samples_split else
                                       f"{STRIPE_ROWS}-row stripes interleaved over {world} ranks") if world > 1 else "full frame",
                        "gather": gather_desc, "gather_transport": group.transport if world > 1 else None,
+                       "gather_root": group.root if world > 1 else None,
+                       # device time of every rank's own frames of the timed region (HIP events on its stream), in rank order; the N-GPU
+                       # job's time is the slowest of them plus what the exchange adds behind it
+                       "rank_region_ms": [round(rank_region[r], 4) for r in sorted(rank_region)] if world > 1 else None,
+                       "slowest_rank": max(rank_region, key=lambda r: rank_region[r]) if world > 1 else None,
+                       # the region's last exchange on the root's stream, from "the root's own frames are done" to the assembled frame
+                       # (okrt_comm_exchange_ms): the wait for slower peers + transfers + de-interleave
+                       "gather_ms_in_region": round(gather_in_region, 4) if gather_in_region is not None else None,
                        "gather_ms": round(exchange_ms, 3) if exchange_ms is not None else None,
                        "gather_bytes_per_peer": tile["bytes"] if world > 1 else None,
                        "host_enqueue_ms_per_launch_set": round(enqueue_ms_per_set, 3),

@@ -1,7 +1,7 @@
 // headless_host_mgpu.cpp — the tile split of config 5 driven by ONE C++ process over every visible GPU, through nothing
 // but include/okrt.h: one okrt context per device, each owning the interleaved 8-row stripes of its rank
 // (okrt_set_tile), the same scene tables uploaded to each, F frames rendered with no per-frame exchange, then ONE
-// gather of the float4 accumulation tiles to device 0 over RCCL / xGMI (okrt_mgpu_gather_accum_all) and render.png from
+// gather of the float4 accumulation tiles to the lightest rank's device over RCCL / xGMI (okrt_mgpu_gather_accum_all) and render.png from
 // the gathered frame. With one visible GPU it degenerates to the single-GPU path (the gather is a device copy).
 //
 //   headless_host_mgpu <width> <height> <frames> <out.png> [max-gpus]
@@ -106,13 +106,25 @@ int main(int argc, char** argv) {
     // every rank traces its stripes of `frames` frames; launches are asynchronous, so the GPUs run concurrently
     for (uint32_t r = 0; r < n; ++r)
         if (!rts[r]->renderFrames(frames)) { std::fprintf(stderr, "render (gpu %u): %s\n", r, rts[r]->lastError().c_str()); return 1; }
-    if (okrt_mgpu_gather_accum_all(ctxs.data(), comms.data(), n, 0, nullptr) != OKRT_OK) {
-        std::fprintf(stderr, "gather: %s\n", okrt_last_error(ctxs[0]));
+    // the root of the gather: the rank that owns the fewest rows (the last one among equals) — it is done with its own frames
+    // first, so the receives and the de-interleave start earliest there
+    uint32_t root = 0, fewest = 0xFFFFFFFFu;
+    for (uint32_t r = 0; r < n; ++r) {
+        uint32_t rows = 0;
+        okrt_tile_rows(ctxs[r], &rows);
+        if (rows <= fewest) fewest = rows, root = r;
+    }
+    if (okrt_mgpu_gather_accum_all(ctxs.data(), comms.data(), n, root, nullptr) != OKRT_OK) {
+        std::fprintf(stderr, "gather: %s\n", okrt_last_error(ctxs[root]));
         return 1;
     }
     std::vector<float> acc((size_t)W * H * 4);
-    if (okrt_mgpu_read_gathered(ctxs[0], comms[0], acc.data()) != OKRT_OK) { std::fprintf(stderr, "read_gathered: %s\n", okrt_last_error(ctxs[0])); return 1; }
-    for (uint32_t r = 1; r < n; ++r) okrt_synchronize(ctxs[r]);
+    if (okrt_mgpu_read_gathered(ctxs[root], comms[root], acc.data()) != OKRT_OK) { std::fprintf(stderr, "read_gathered: %s\n", okrt_last_error(ctxs[root])); return 1; }
+    float exchangeMs = 0.f;
+    okrt_comm_exchange_ms(comms[root], &exchangeMs);
+    std::fprintf(stderr, "gather onto rank %u (%u rows): %.3f ms on its stream\n", root, fewest, exchangeMs);
+    for (uint32_t r = 0; r < n; ++r)
+        if (r != root) okrt_synchronize(ctxs[r]);
 
     // resolve like the shader: saturate(acc / N) -> UNORM8 (RaytracerCS.hlsl:526-536)
     std::vector<uint8_t> rgba((size_t)W * H * 4);

@@ -11,7 +11,7 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 
-OKRT_ABI_VERSION = 3
+OKRT_ABI_VERSION = 4
 
 # okrt_table slots = the reference's t-registers (ShaderResourceRegisters.h:9-21)
 TABLE_TRI_POS, TABLE_TRI_INFO, TABLE_BVH = 0, 1, 2
@@ -111,6 +111,7 @@ PRODUCT_ONLY = {
     "mgpu_reduce_accum_all": (C.c_int, [C.POINTER(P), C.POINTER(P), U32, U32, P]),
     "peek_result_rgba8": (C.c_int, [P, P, C.POINTER(U32)]),
     "frame_size": (C.c_int, [P, C.POINTER(U32), C.POINTER(U32)]),
+    "comm_exchange_ms": (C.c_int, [P, C.POINTER(C.c_float)]),
 }
 KAT_PCG_HASH, KAT_RANDOM_FLOAT, KAT_RAY_SPHERE, KAT_RAY_TRIANGLE, KAT_RAY_AABB, KAT_REFRACT, KAT_SAMPLE_TEXTURE, KAT_SAMPLE_ENV, KAT_CLOSEST_HIT, KAT_CLOSEST_HIT_FAST = range(10)
 KAT_RANDOM_VECTOR, KAT_REFLECTANCE, KAT_REFLECT_DIRECTION, KAT_TRANSPARENCY_BOUNCE, KAT_PRIMARY_RAY = range(10, 15)

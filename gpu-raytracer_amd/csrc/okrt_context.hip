@@ -1259,7 +1259,8 @@ const okrt_api* okrt_get_api(void) {
                                  okrt_comm_destroy,    okrt_comm_last_error, okrt_mgpu_gather_accum, okrt_mgpu_gather_accum_all,
                                  okrt_mgpu_read_gathered, okrt_mgpu_deinterleave,
                                  okrt_device_count,    okrt_comm_transport, okrt_mgpu_reduce_accum, okrt_mgpu_reduce_accum_all,
-                                 okrt_peek_result_rgba8, okrt_frame_size};
+                                 okrt_peek_result_rgba8, okrt_frame_size,
+                                 okrt_comm_exchange_ms};
     return &api;
 }
 

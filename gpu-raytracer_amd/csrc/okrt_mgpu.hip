@@ -110,6 +110,8 @@ struct okrt_comm {
     int device = 0;
     bool copyTransport = false;
     hipEvent_t ready = nullptr, done = nullptr;  // copy transport: "my frames are rendered" / "the root has my tile"
+    hipEvent_t xBegin = nullptr, xEnd = nullptr;  // root: around the last gather / reduce on its stream (okrt_comm_exchange_ms)
+    bool xRecorded = false;
     float4* staging = nullptr;  // root: nranks tiles of maxRows rows (gather) or one full frame (reduce, copy transport)
     size_t stagingBytes = 0;
     float4* full = nullptr;     // root: library-owned full frame
@@ -267,6 +269,35 @@ const char* okrt_comm_transport(const okrt_comm* comm) {
     return comm->nranks == 1 ? "single" : comm->copyTransport ? "copy" : "rccl";
 }
 
+// okrt_comm_exchange_ms: the root brackets an exchange with two events on its own stream — from "my frames are rendered" (the
+// exchange is enqueued behind them) to "the full frame is assembled": the peers' remaining render time it has to wait for, the
+// transfers and the de-interleave. Timing failures never fail the exchange.
+static void exchangeBegin(okrt_comm* c, const CtxFrame& f) {
+    c->xRecorded = false;
+    if (hipSetDevice(f.device) != hipSuccess) return;
+    if (!c->xBegin && (hipEventCreate(&c->xBegin) != hipSuccess || hipEventCreate(&c->xEnd) != hipSuccess)) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (hipEventRecord(c->xBegin, f.stream) != hipSuccess) (void)hipGetLastError();
+}
+static void exchangeEnd(okrt_comm* c, const CtxFrame& f) {
+    if (!c->xBegin || !c->xEnd || hipSetDevice(f.device) != hipSuccess) return;
+    if (hipEventRecord(c->xEnd, f.stream) == hipSuccess) c->xRecorded = true;
+    else (void)hipGetLastError();
+}
+
+okrt_status okrt_comm_exchange_ms(okrt_comm* c, float* out_ms) {
+    if (!c || !out_ms) return OKRT_ERR_INVALID_ARG;
+    *out_ms = 0.f;
+    if (!c->xRecorded) return commFail(c, OKRT_ERR_STATE, "exchange_ms: this rank was not the root of a gather / reduce yet");
+    if (hipSetDevice(c->device) != hipSuccess || hipEventSynchronize(c->xEnd) != hipSuccess || hipEventElapsedTime(out_ms, c->xBegin, c->xEnd) != hipSuccess) {
+        (void)hipGetLastError();
+        return commFail(c, OKRT_ERR_DEVICE, "exchange_ms: reading the events failed");
+    }
+    return OKRT_OK;
+}
+
 okrt_status okrt_device_count(int* out_count) {
     if (!out_count) return OKRT_ERR_INVALID_ARG;
     *out_count = 0;
@@ -368,6 +399,8 @@ okrt_status okrt_comm_destroy(okrt_comm* c) {
     if (c->comm) rccl().CommDestroy(c->comm);
     if (c->ready) hipEventDestroy(c->ready);
     if (c->done) hipEventDestroy(c->done);
+    if (c->xBegin) hipEventDestroy(c->xBegin);
+    if (c->xEnd) hipEventDestroy(c->xEnd);
     if (c->staging) hipFree(c->staging);
     if (c->full) hipFree(c->full);
     delete c;
@@ -381,6 +414,7 @@ okrt_status okrt_mgpu_gather_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* 
     const uint32_t nranks = comms[0]->nranks;
     const TileView& t0 = p.fr[0].tile;
     const size_t rowBytes = (size_t)t0.W * sizeof(float4);
+    if (p.rootSlot < n) exchangeBegin(comms[p.rootSlot], p.fr[p.rootSlot]);
     if (p.rootSlot < n) {  // the root's own tile: a device copy, outside any group
         const CtxFrame& rf = p.fr[p.rootSlot];
         if (rf.tile.rows && (hipSetDevice(rf.device) != hipSuccess ||
@@ -418,6 +452,7 @@ okrt_status okrt_mgpu_gather_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* 
     if (p.rootSlot < n) {
         st = deinterleaveOnRoot(ctxs[p.rootSlot], comms[p.rootSlot], p.fr[p.rootSlot], p.maxRows, fullFrameDev);
         if (st == OKRT_OK && nranks > 1 && p.copy) st = releasePeers(ctxs[p.rootSlot], p, comms);
+        if (st == OKRT_OK) exchangeEnd(comms[p.rootSlot], p.fr[p.rootSlot]);
     }
     return st;
 }
@@ -438,6 +473,7 @@ okrt_status okrt_mgpu_reduce_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* 
     const size_t px = (size_t)t0.W * t0.H;
     float4* dst = nullptr;
     if (p.rootSlot < n) dst = fullFrameDev ? (float4*)fullFrameDev : comms[p.rootSlot]->full;
+    if (p.rootSlot < n) exchangeBegin(comms[p.rootSlot], p.fr[p.rootSlot]);
     if (nranks == 1 || p.copy) {
         const CtxFrame& rf = p.fr[p.rootSlot];
         if (hipSetDevice(rf.device) != hipSuccess || hipMemcpyAsync(dst, rf.accum, px * sizeof(float4), hipMemcpyDeviceToDevice, rf.stream) != hipSuccess)
@@ -449,7 +485,9 @@ okrt_status okrt_mgpu_reduce_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* 
             hipLaunchKernelGGL(addFramesKernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, rf.stream, dst, comms[p.rootSlot]->staging, px);
             if (hipGetLastError() != hipSuccess) return ctxFail(ctxs[p.rootSlot], OKRT_ERR_DEVICE, "mgpu reduce: launch failed");
         }
-        return nranks > 1 ? releasePeers(ctxs[p.rootSlot], p, comms) : OKRT_OK;
+        st = nranks > 1 ? releasePeers(ctxs[p.rootSlot], p, comms) : OKRT_OK;
+        if (st == OKRT_OK) exchangeEnd(comms[p.rootSlot], rf);
+        return st;
     }
     if (!ncclOk(comms[0], rccl().GroupStart(), "ncclGroupStart")) return ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
     for (uint32_t k = 0; k < n && st == OKRT_OK; ++k)
@@ -457,6 +495,7 @@ okrt_status okrt_mgpu_reduce_accum_all(okrt_ctx* const* ctxs, okrt_comm* const* 
         else if (!ncclOk(comms[k], rccl().Reduce(p.fr[k].accum, k == p.rootSlot ? (void*)dst : nullptr, px * 4, ncclFloat, ncclSum, (int)root, comms[k]->comm, p.fr[k].stream), "ncclReduce"))
             st = ctxFail(ctxs[k], OKRT_ERR_DEVICE, comms[k]->err);
     if (!ncclOk(comms[0], rccl().GroupEnd(), "ncclGroupEnd") && st == OKRT_OK) st = ctxFail(ctxs[0], OKRT_ERR_DEVICE, comms[0]->err);
+    if (st == OKRT_OK && p.rootSlot < n) exchangeEnd(comms[p.rootSlot], p.fr[p.rootSlot]);
     return st;
 }
 

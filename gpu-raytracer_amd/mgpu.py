@@ -181,10 +181,14 @@ class TileGroup:
     of the job. `gather()` / `reduce()` are collective over the whole job and asynchronous on the contexts' streams
     (the host-memory rehearsal excepted: it reads the tiles back)."""
 
-    def __init__(self, fns, plan, ctx_handles, store=None, frame=None, read_tile=None):
+    def __init__(self, fns, plan, ctx_handles, store=None, frame=None, read_tile=None, root=None):
         """frame = (width, height, stripe_rows); read_tile(k) -> packed float accumulation of local context k (only the
-        host-memory rehearsal and the one-rank case use it)."""
+        host-memory rehearsal and the one-rank case use it). root: the rank the exchanges deliver to; default = the rank that
+        owns the fewest rows of the striped split (tiling.lightest_rank), rank 0 when the frame is not given."""
         self.fns, self.plan, self.store = fns, plan, store
+        if root is None:
+            root = tiling.lightest_rank(frame[1], frame[2], plan["world"]) if frame and plan["world"] > 1 else 0
+        self.root = int(root)
         self.h = list(ctx_handles)
         self.n = len(self.h)
         self.world = plan["world"]
@@ -222,7 +226,21 @@ class TileGroup:
 
     @property
     def is_root(self):
-        return 0 in self.plan["local_ranks"]
+        return self.root in self.plan["local_ranks"]
+
+    @property
+    def root_local(self):
+        """Index of the root's context among the ones this process drives (is_root must hold)."""
+        return list(self.plan["local_ranks"]).index(self.root)
+
+    def exchange_ms(self):
+        """Root only: device time of the last gather / reduce on the root's stream (okrt_comm_exchange_ms); None elsewhere and
+        for the host-memory rehearsal."""
+        if not self.is_root or not self.comms:
+            return None
+        ms = C.c_float(0)
+        st = self.fns.comm_exchange_ms(self.comms[self.root_local], C.byref(ms))
+        return float(ms.value) if st == 0 else None
 
     @property
     def host_only(self):
@@ -243,29 +261,29 @@ class TileGroup:
         self._host_full = np.sum(np.stack(tiles), axis=0, dtype=np.float32) if samples_split else tiling.deinterleave(tiles, height, stripe_rows)
 
     def gather(self):
-        """Tile split: every rank's packed float4 tile -> the full frame on rank 0 (read_full())."""
+        """Tile split: every rank's packed float4 tile -> the full frame on the root (read_full())."""
         if self.world == 1:
             return
         if self.host_only:
             self._through_host(False)
         elif self.plan["mode"] == "one_process":
-            self._ck(self.fns.mgpu_gather_accum_all(self._ctx_arr, self._comm_arr, self.n, 0, None), "okrt_mgpu_gather_accum_all")
+            self._ck(self.fns.mgpu_gather_accum_all(self._ctx_arr, self._comm_arr, self.n, self.root, None), "okrt_mgpu_gather_accum_all")
         else:
-            self._ck(self.fns.mgpu_gather_accum(self.h[0], self.comms[0], 0, None), "okrt_mgpu_gather_accum")
+            self._ck(self.fns.mgpu_gather_accum(self.h[0], self.comms[0], self.root, None), "okrt_mgpu_gather_accum")
 
     def reduce(self):
-        """Samples split: sum of the whole-frame accumulations on rank 0 (read_full())."""
+        """Samples split: sum of the whole-frame accumulations on the root (read_full())."""
         if self.world == 1:
             return
         if self.host_only:
             self._through_host(True)
         elif self.plan["mode"] == "one_process":
-            self._ck(self.fns.mgpu_reduce_accum_all(self._ctx_arr, self._comm_arr, self.n, 0, None), "okrt_mgpu_reduce_accum_all")
+            self._ck(self.fns.mgpu_reduce_accum_all(self._ctx_arr, self._comm_arr, self.n, self.root, None), "okrt_mgpu_reduce_accum_all")
         else:
-            self._ck(self.fns.mgpu_reduce_accum(self.h[0], self.comms[0], 0, None), "okrt_mgpu_reduce_accum")
+            self._ck(self.fns.mgpu_reduce_accum(self.h[0], self.comms[0], self.root, None), "okrt_mgpu_reduce_accum")
 
     def read_full(self):
-        """Rank 0: the combined H x W x 4 frame of the last gather / reduce (synchronises). Other ranks: None."""
+        """On the root's process: the combined H x W x 4 frame of the last gather / reduce (synchronises). Elsewhere: None."""
         if not self.is_root:
             return None
         width, height, _ = self.frame
@@ -274,7 +292,8 @@ class TileGroup:
         if self.host_only:
             return self._host_full
         out = np.empty((height, width, 4), np.float32)
-        self._ck(self.fns.mgpu_read_gathered(self.h[0], self.comms[0], out.ctypes.data_as(P)), "okrt_mgpu_read_gathered")
+        k = self.root_local
+        self._ck(self.fns.mgpu_read_gathered(self.h[k], self.comms[k], out.ctypes.data_as(P)), "okrt_mgpu_read_gathered")
         return out
 
     def close(self):

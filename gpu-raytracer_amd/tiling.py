@@ -17,6 +17,15 @@ def owned_rows(height, stripe_rows, rank, world):
     return np.asarray(rows, dtype=np.int64)
 
 
+def lightest_rank(height, stripe_rows, world):
+    """The rank that owns the fewest rows of the striped split (the last one among equals): the natural ROOT of the gather — it
+    finishes its own frames first, so the root-side work (own-tile copy, receives, de-interleave) starts earliest there.
+    1080 rows in 8-row stripes over 8 ranks: ranks 0-6 own 136 rows, rank 7 owns 128."""
+    rows = [len(owned_rows(height, stripe_rows, r, world)) for r in range(world)]
+    least = min(rows)
+    return max(r for r in range(world) if rows[r] == least)
+
+
 def max_owned_rows(height, stripe_rows, world):
     return max(len(owned_rows(height, stripe_rows, r, world)) for r in range(world))
 

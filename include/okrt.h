@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define OKRT_ABI_VERSION 3
+#define OKRT_ABI_VERSION 4
 
 typedef struct okrt_ctx okrt_ctx;
 
@@ -428,6 +428,11 @@ okrt_status okrt_comm_create(okrt_ctx* ctx, const uint8_t id[OKRT_COMM_ID_BYTES]
 okrt_status okrt_comm_create_all(okrt_ctx* const* ctxs, uint32_t n, okrt_comm** out_comms);
 okrt_status okrt_comm_destroy(okrt_comm* comm);
 const char* okrt_comm_last_error(const okrt_comm* comm); /* comm == NULL: why the last create on this thread failed */
+/* On the root of the most recent okrt_mgpu_gather_accum[_all] / okrt_mgpu_reduce_accum[_all]: device time on the root's stream
+ * from the point where the exchange was enqueued (behind the root's own frames) to the assembled full frame — what the root
+ * waited for its peers, the transfers, the de-interleave. Synchronises with that exchange only. OKRT_ERR_STATE on a
+ * communicator that has not been a root yet. (No reference counterpart: the reference renders on one GPU, RayTracer.cpp:256.) */
+okrt_status okrt_comm_exchange_ms(okrt_comm* comm, float* out_ms);
 /* Collective over the communicator. Every context must have the same frame size and the tile (stripe_rows, rank, nranks)
  * of its rank. On `root`, full_frame_dev (device memory, H * W float4; NULL = a library-owned buffer, read it with
  * okrt_mgpu_read_gathered) receives the whole accumulation, row 0 = top. Asynchronous on each context's stream. */
@@ -502,6 +507,8 @@ typedef struct okrt_api {
     okrt_status (*mgpu_reduce_accum_all)(okrt_ctx* const*, okrt_comm* const*, uint32_t, uint32_t, void*);
     okrt_status (*peek_result_rgba8)(okrt_ctx*, uint8_t*, uint32_t*);
     okrt_status (*frame_size)(const okrt_ctx*, uint32_t*, uint32_t*);
+    /* ABI 4 */
+    okrt_status (*comm_exchange_ms)(okrt_comm*, float*);
 } okrt_api;
 
 const okrt_api* okrt_get_api(void);

@@ -33,10 +33,11 @@ def api_table_entries():
 def test_api_table_is_complete(oracle):
     """ABI 2+: the okrt_api table carries the WHOLE surface; the product fills every entry, and every declared okrt_*
     entry point (bar create-time helpers that cannot go through a table) has one. ABI 3 appended six entries (device
-    count, transport name, the samples-split reduce, peek, frame size) behind the 41 of ABI 2: older hosts keep working."""
+    count, transport name, the samples-split reduce, peek, frame size) behind the 41 of ABI 2, ABI 4 one more (the root's
+    exchange time): older hosts keep working."""
     names = api_table_entries()
-    assert len(names) == 47 and len(set(names)) == len(names)
-    assert names[41:] == ["device_count", "comm_transport", "mgpu_reduce_accum", "mgpu_reduce_accum_all", "peek_result_rgba8", "frame_size"]
+    assert len(names) == 48 and len(set(names)) == len(names)
+    assert names[41:] == ["device_count", "comm_transport", "mgpu_reduce_accum", "mgpu_reduce_accum_all", "peek_result_rgba8", "frame_size", "comm_exchange_ms"]
     lib = C.CDLL(abi.device_library_path())
     lib.okrt_get_api.restype = C.POINTER(C.c_void_p * (len(names) + 1))
     table = lib.okrt_get_api().contents

@@ -118,6 +118,8 @@ def _tile_rank(rank, world, key, root, out_path):
     rt.ctx.set_tile(SR, rank, world)
     group = m.TileGroup(oracle.fns, plan, [rt.ctx.h], store, frame=(W, H, SR), read_tile=lambda k: rt.ctx.read_accum())
     assert group.host_only and "REHEARSAL" in group.transport
+    # the root is the rank with the fewest rows, the last one among equals: 27 rows in 4-row stripes -> 15 / 12 rows (2 ranks), 11 / 8 / 8 (3)
+    assert group.root == {2: 1, 3: 2}[world] and group.is_root == (rank == group.root)
     rt.renderFrames(FRAMES)
     group.gather()
     full = group.read_full()
@@ -128,7 +130,7 @@ def _tile_rank(rank, world, key, root, out_path):
     rt.renderFrames(2)
     group.reduce()
     summed = group.read_full()
-    if rank == 0:
+    if group.is_root:
         ref_rt, _, _ = oracle.instantiate(desc, W, H)
         ref_rt.renderFrames(FRAMES)
         ref = ref_rt.ctx.read_accum()
@@ -142,6 +144,20 @@ def _tile_rank(rank, world, key, root, out_path):
         assert full is None and summed is None
     group.close()
     store.close()
+
+
+def test_the_gather_root_is_the_lightest_rank():
+    """bench.py, mgpu.TileGroup and examples/headless_host_mgpu.cpp deliver the tiles to the rank that owns the fewest rows (it is
+    done with its own frames first): rank N - 1 for 1080 rows in 8-row stripes over 8 ranks (128 rows against 136)."""
+    t = importlib.import_module("gpu-raytracer_amd.tiling")
+    assert t.lightest_rank(1080, 8, 8) == 7 and [len(t.owned_rows(1080, 8, r, 8)) for r in (0, 6, 7)] == [136, 136, 128]
+    assert t.lightest_rank(1080, 8, 4) == 3 and t.lightest_rank(1080, 8, 2) == 1
+    assert t.lightest_rank(2160, 8, 8) == 7  # 270 stripes: ranks 0-5 own 34, ranks 6 and 7 own 33: the last of the equals
+    assert t.lightest_rank(64, 8, 8) == 7 and t.lightest_rank(64, 8, 1) == 0
+    assert t.lightest_rank(20, 8, 8) == 7  # ranks that own nothing at all
+    for world in (2, 3, 5, 8):
+        rows = [len(t.owned_rows(1080, 8, r, world)) for r in range(world)]
+        assert rows[t.lightest_rank(1080, 8, world)] == min(rows)
 
 
 @pytest.mark.parametrize("world", [2, 3])
