@@ -234,8 +234,13 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         term1 = terminal and mb == 1
         cam_alg = (56 + (16 if term1 else 0)) * cam_surv + slot * max(pixels - cam_surv, 0) + 64 * cam_hits + 16 * cam_taps + 16 * cam_env
         cam_l2 = (64 * cam_nodes + 48 * cam_tris) / 64 + cam_alg
-        add("tracePacketKernel<FUSED> (camera segment: generate + packet traversal + shade + append)", interval_ms[0] + interval_ms[1], cam_alg, cam_l2,
-            structure_bytes, 0)
+        if build["flags"] & 8:  # OKRT_BUILD_FLAG_CAMERA_PER_RAY: the probe chose the per-ray kernel (three launches, queue 0 and hit records in between)
+            cam_alg += (32 + 32 + 20 + 20 + 32) * pixels  # generate writes 32 B per ray, traceKernel reads them + writes 20, shadeKernel<FIRST> reads 32 + 20
+            add("traceKernelCamera + generateKernel + shadeKernel<FIRST> (camera segment traced per ray: chosen by the probe for this scene)",
+                interval_ms[0] + interval_ms[1], cam_alg, 64 * cam_nodes + 48 * cam_tris + cam_alg, structure_bytes, (32 + 32 + 20) * pixels)
+        else:
+            add("tracePacketKernel<FUSED> (camera segment: generate + packet traversal + shade + append)", interval_ms[0] + interval_ms[1], cam_alg, cam_l2,
+                structure_bytes, 0)
         if mb >= 1 and len(interval_ms) >= 4:
             tr = sum(interval_ms[2::2])
             sh = sum(interval_ms[3::2])
@@ -278,6 +283,15 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                 k["traffic_frac"] = round(m["hbm_bytes_per_launch"] / (k["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 k["l2_hit_pct"] = m.get("l2_hit_pct")
                 k["valu_lane_util"] = m.get("valu_lane_util")
+                # issue-rate roofline (tools/pmc_traffic.py pass sq2; ceilings measured by tools/calib/issue_rate.hip -> profiles/r05_issue_rate.txt:
+                # a SIMD starts at most ONE vector instruction per quad-cycle — min / max / select / compare / convert all measure 0.96-0.98, only
+                # v_fma_f32 dual-rates to 1.55-1.77 — and one scalar instruction beside it): instructions of the kind / (SIMDs x kernel quad-cycles)
+                for key in ("valu_issue_frac", "valu_busy_frac", "salu_issue_frac", "scalar_busy_frac", "vmem_issue_frac", "lds_issue_frac"):
+                    if m.get(key) is not None:
+                        k[key] = m[key]
+                if m.get("wait_any_share") is not None:
+                    k["wait_mem_share"] = m["wait_any_share"]      # wave quad-cycles parked in s_waitcnt / barriers
+                    k["wait_issue_share"] = m.get("wait_inst_share")  # ... ready but not issued (the port was taken)
                 if m.get("l2_read_requests_per_launch"):
                     req = m["l2_read_requests_per_launch"]
                     k["l2_read_requests_per_launch"] = int(req)
@@ -287,9 +301,14 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                     k["l2_frac"] = round(per_s * 128 / 1e9 / L2_PEAK_GBS, 4)
                     # against what a pure gather with the same L2 hit rate reaches — for the kernels whose requests ARE gathers (the shading
                     # kernels also stream their queues, whole 128-byte lines at a higher rate than any gather: the ceiling does not apply)
-                    if m.get("l2_hit_pct") is not None and short in ("traceKernel", "tracePacketKernel"):
+                    if m.get("l2_hit_pct") is not None and short in ("traceKernel", "tracePacketKernel", "traceKernelCamera"):
                         k["gather_ceiling_frac"] = round(per_s / gather_ceiling(m["l2_hit_pct"] / 100.0), 4)
         traffic, lane_util, l2_hit = head.get("traffic"), head.get("valu_lane_util"), head.get("l2_hit_pct")
+        for k in kernels:  # what binds each kernel, from its own measured fractions (the largest one names it)
+            cands = {"valu-issue": k.get("valu_issue_frac") or 0.0, "gather (L1 -> L2 request rate of the memory hierarchy)": k.get("gather_ceiling_frac") or 0.0,
+                     "fabric (L2 <-> Infinity Cache / HBM bytes)": k.get("traffic_frac") or 0.0}
+            best = max(cands, key=lambda n: cands[n])
+            k["bound"] = best if cands[best] >= 0.5 else "latency (no resource above half of its ceiling: short dependent launches)"
     measured = traffic is not None
     achieved = (traffic if measured else head["algorithmic_bytes_per_launch"]) / (head["launch_ms"] * 1e-3) / 1e9
     return {
@@ -304,18 +323,25 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         "traffic_source": pmc[0] if pmc else why,
         "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "algorithmic_frac": head["algorithmic_frac"],
         "l2_frac": head["l2_frac"], "gather_ceiling_frac": head["gather_ceiling_frac"], "l2_hit_pct": l2_hit, "valu_lane_util": lane_util,
+        # the dominant kernel's binding resource (kernels[].bound): `bound` above stays the HBM roofline the contract asks for
+        "binding_resource": head.get("bound"), "valu_issue_frac": head.get("valu_issue_frac"), "salu_issue_frac": head.get("salu_issue_frac"),
+        "issue_ceiling": "one VALU instruction per SIMD quad-cycle (measured 0.96-0.98 for min / max / select / compare / convert; v_fma_f32 alone 1.55-1.77) "
+                         "and one SALU instruction beside it: tools/calib/issue_rate.hip -> profiles/r05_issue_rate.txt",
         "kernels": kernels,
         "node4q_visits_per_bounce_ray": round(b_nodes / max(bounce_rays, 1), 2), "tri48_tests_per_bounce_ray": round(b_tris / max(bounce_rays, 1), 2),
+        # (wave-level counts under the packet kernel; under the per-ray camera kernel the same expression is the average per RAY)
         "node4q_steps_per_camera_tile": round(cam_nodes / 64 / max(pixels / 64, 1), 2), "tri48_tests_per_camera_tile": round(cam_tris / 64 / max(pixels / 64, 1), 2),
+        "camera_segment": "per ray (probe)" if build["flags"] & 8 else "8x8 packets",
         "structure_bytes": structure_bytes,
         "traversal_ms_per_frame": round(trace_ms_frame, 4), "later_shading_ms_per_frame": round(shade_ms_frame, 4), "other_ms_per_frame": round(other_ms_frame, 4),
         # SURVEY.md §8d to the letter, kept under its own name: the bytes the REFERENCE's octree -> mesh -> BVH order would touch
         # for these rays over the traversal time. Far above 1: it measures the work the derived structure avoids, not a bandwidth.
         "reference_work_ratio": round(ref_trav_bytes / per_gpu / max(trace_ms_frame * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 2),
         "reference_algorithmic_bytes_per_ray": round(ref_trav_bytes / max(ref_c["segments"], 1), 1),
-        "note": "frac <= 1 by construction. The traversal kernels are VALU-issue / latency bound (dependent gathers served by L1, L2 and the Infinity Cache: "
-                "the structure is cache-resident; gather_ceiling_frac = their measured L1 -> L2 read requests against the rate a pure gather with the same L2 hit rate reaches: close to 1 on the 871 k-triangle scene), so their fabric fraction is low; the later-segment shading kernels move the most bytes per second "
-                "(kernels[].traffic_frac), a fabric / Infinity-Cache rate on this working set, not proven HBM.",
+        "note": "frac <= 1 by construction. kernels[].bound names what binds each kernel: on a cache-resident structure the traversal kernels fill the SIMDs' vector "
+                "issue port (valu_issue_frac ~ 1 of one instruction per SIMD quad-cycle, at valu_lane_util of the lanes), so their fabric fraction is low; on structures "
+                "beyond the caches (871 k / 8 M triangles) they run at the memory hierarchy's gather rate (gather_ceiling_frac ~ 1); the streaming kernels move the most "
+                "bytes per second (traffic_frac), a fabric / Infinity-Cache rate on this working set, not proven HBM.",
     }
 
 

@@ -62,6 +62,7 @@ struct FastHostScene {
     std::vector<Tri48> tris;
     uint32_t maxDepth = 0;     // deepest leaf, in Node4Q levels
     bool allIdentity = true;   // every instance matrix is the identity (bit-exact with the reference order)
+    bool consistent = true;    // false: the collapse met an impossible table and could not place every subtree (the build is refused)
 };
 void buildFastHost(const FastInputs& in, FastHostScene& out);
 

@@ -254,6 +254,7 @@ struct Emitter {
     std::vector<float> cost;       // [node][i], i = 1..3 at [4 * node + i]
     std::vector<uint8_t> choice;   // [4 * node + i]: i = 1: roots the left half gets (1..3); i > 1: 0 = as for i - 1, else roots for the left half
     bool optimal = false;
+    mutable bool broken = false;  // forest() met a collapse table that would have dropped a subtree: the build is refused (fastBuild)
 
     void solve(int32_t root) {
         static const float kWideNodeCost = getenv("OKRT_BUILD_WIDE_NODE_COST") ? (float)atof(getenv("OKRT_BUILD_WIDE_NODE_COST")) : 1.0f;
@@ -311,9 +312,17 @@ struct Emitter {
             out[count++] = n;
             return;
         }
-        const uint8_t k = choice[4 * (size_t)n + i];
-        if (i < 1 || i > 3 || k >= i || count >= 4) {  // cannot happen with the tables solve() fills; a malformed table must not recurse or overrun kids[4]
+        // cannot happen with the tables solve() fills (i in 2..3 here, 0 <= choice < i, at most four roots in all): a malformed table
+        // must neither index outside its node's four entries, nor recurse for ever, nor overrun kids[4] — and must not LOSE a subtree
+        // either: the whole of n then goes out as one root while there is room, and the build is marked broken when there is none
+        if (i < 2 || i > 3 || count >= 4) {
             if (count < 4) out[count++] = n;
+            else broken = true;
+            return;
+        }
+        const uint8_t k = choice[4 * (size_t)n + i];
+        if (k >= i) {
+            out[count++] = n;
             return;
         }
         if (k == 0) forest(n, i - 1, out, count);
@@ -458,6 +467,7 @@ void buildFastHost(const FastInputs& in, FastHostScene& out) {
     if (kOptimalCollapse) e.solve((int32_t)r);
     e.emitNode(0, (int32_t)r, 1);
     out.maxDepth = e.maxDepth;
+    out.consistent = !e.broken;
 }
 
 // ---- top of the tree for the device builder ---------------------------------------------------------------------------

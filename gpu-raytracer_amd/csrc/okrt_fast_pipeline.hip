@@ -129,6 +129,10 @@ bool fastBuild(FastScene** scene, const FastInputs& in, const FastDeviceTables& 
     } else {
         FastHostScene host;
         buildFastHost(in, host);
+        if (!host.consistent) {
+            err = "host builder: inconsistent collapse table (a subtree could not be placed)";
+            return false;
+        }
         fs.numNodes = (uint32_t)host.nodes.size();
         fs.numTris = (uint32_t)host.tris.size();
         fs.maxDepth = host.maxDepth;

@@ -131,10 +131,14 @@ class FileStore:
         import struct
         if getattr(self, "_bar", None) is None:
             path = os.path.join(self.dir, "tight_barrier")
-            fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+            # a directory reused under the same OKRT_RDZV_KEY may hold an old file with large counters, which would let the first
+            # rounds pass without waiting: rank 0 writes a zeroed file first, the others map it only after an ordinary barrier
+            if self.rank == 0:
+                with open(path, "wb") as f:
+                    f.write(b"\0" * (64 * self.world))
+            self.barrier()
+            fd = os.open(path, os.O_RDWR)
             try:
-                if os.fstat(fd).st_size < 64 * self.world:
-                    os.ftruncate(fd, 64 * self.world)  # (idempotent: every rank may do it; new bytes are zero)
                 self._bar = mmap.mmap(fd, 64 * self.world)
             finally:
                 os.close(fd)
@@ -148,14 +152,21 @@ class FileStore:
             spins = 0
             while struct.unpack_from("<Q", self._bar, 64 * r)[0] < self._bar_round:
                 spins += 1
-                if spins & 0xFFF == 0 and time.monotonic() > deadline:
-                    raise TimeoutError(f"rank {self.rank}: rank {r} never reached tight barrier {self._bar_round}")
+                if spins & 0xFFF == 0:
+                    now = time.monotonic()
+                    if now > deadline:
+                        raise TimeoutError(f"rank {self.rank}: rank {r} never reached tight barrier {self._bar_round}")
+                    if now - (deadline - self.timeout) > 0.005:
+                        time.sleep(0.0005)  # a peer that is milliseconds late is not about to arrive within microseconds: stop burning the core
 
     def close(self):
         """Collective. After a last barrier (every rank has finished every earlier read) each rank signs off; rank 0
         waits for all sign-offs — nobody reads after writing theirs — and removes the directory."""
         import shutil
         self.barrier()
+        if getattr(self, "_bar", None) is not None:
+            self._bar.close()
+            self._bar = None
         self.set(f"bye.{self.rank}", b"")
         if self.rank == 0:
             for r in range(self.world):

@@ -59,6 +59,10 @@ def family(name):
     args = [a.strip() for a in (m.group(3) or "").split(",")] if m.group(3) else []
     fam = m.group(1)
     counting = (fam in ("tracePacketKernel", "traceKernel") and args[:1] == ["true"]) or (fam == "shadeKernel" and args[1:2] == ["true"])
+    # traceKernel<COUNT, MODE>: MODE 0 = full hit record, 1 / 2 = the last segment's hit-or-miss form. A launch set that holds both is one
+    # whose CAMERA segment is traced per ray (MODE 0) in front of the last segment (MODE 1): kept apart, renamed in main()
+    if fam == "traceKernel" and args[1:2] == ["0"]:
+        fam = "traceKernel0"
     return fam, counting
 
 
@@ -105,8 +109,11 @@ def main():
                     # (SQ_INSTS_VALU rides both SQ passes: pass sq2's copy sits beside GRBM_GUI_ACTIVE, i.e. the same launches' clock)
                     cname = r["Counter_Name"] + ("@sq2" if name == "sq2" and r["Counter_Name"] == "SQ_INSTS_VALU" else "")
                     ctr[fam][cname].append(float(r["Counter_Value"]))
+    for table in (dur, ctr):  # (see family(): MODE 0 beside MODE 1 = the per-ray camera segment; MODE 0 alone = every bounce segment)
+        if "traceKernel0" in table:
+            table["traceKernelCamera" if "traceKernel" in table else "traceKernel"] = table.pop("traceKernel0")
     kernels = {}
-    for fam in FAMILIES:
+    for fam in FAMILIES + ("traceKernelCamera",):
         if fam not in dur and fam not in ctr:
             continue
         avg = {c: sum(v) / len(v) for c, v in ctr[fam].items()}
