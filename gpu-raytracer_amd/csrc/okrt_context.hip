@@ -83,7 +83,7 @@ struct okrt_ctx {
     // its fixed cost — the last dependent chains of every kernel on an emptied GPU — is a fifth of its time there, and the
     // next sub-set's bulk fills the GPU meanwhile. Above splitRays rays per set the contention costs more than it returns.
     uint64_t splitRays = kPipelineSplitRays;
-    uint32_t splitParts = 2;
+    uint32_t splitParts = 1;  // (round 5: with the camera tiles issued longest first the tail the sub-sets were hiding is gone: one set is faster; OKRT_PIPELINE_SPLIT_PARTS=2 restores them)
     // okrt_peek_result_rgba8: two device-side copies of the resolved picture, refreshed alternately at the end of every
     // launch set once a host has asked for one; the peek copies the newest finished one out on its own stream
     bool peekOn = false;

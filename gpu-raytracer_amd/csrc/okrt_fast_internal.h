@@ -157,6 +157,11 @@ struct FusedArgs {
     float4* radiance;
     const okrt_render_data* rdDev;  // the same RenderData in device memory: read where it is used instead of being held in SGPRs across the tile loop
     uint32_t terminalNext;    // 1 = the survivors' next segment is the last one of a scene where a hit there adds nothing (traceKernel MODE 1)
+    // longest tiles first: tileOrder[r] = the tile of cost rank r (nullptr = frame-major order), tileCost[t] = node steps + triangle
+    // tests tile t took in frame 0 of this set (what orderTilesKernel ranks the NEXT set by), frames = frames of this launch set
+    const uint32_t* tileOrder;
+    uint32_t* tileCost;
+    uint32_t frames;
 };
 
 // ---- launch wrappers (one per kernel family; `count` selects the variant that feeds okrt_counters) --------------------
@@ -171,6 +176,9 @@ void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const Sc
                  float4* accum, uint32_t* result, float4* radiance, unsigned long long* counters, uint32_t terminalNext);
 // the misses of a last segment traced with traceKernel MODE 1 / 2: environment lookup into the pixel's radiance slot
 void launchMiss(dim3 grid, hipStream_t stream, const SceneView& s, RayQueue qIn, const ShardView& in, float4* radiance);
+// ranks the camera tiles of a launch set by the step count they took last time (descending) and writes the per-shard ray counts
+// of the longest-first layout (FusedArgs::tileOrder)
+void launchOrderTiles(hipStream_t stream, const uint32_t* tileCost, uint32_t tiles, uint32_t frames, uint32_t* order, uint32_t* keys, uint32_t* shardCounts);
 void launchSetRenderData(hipStream_t stream, const okrt_render_data& rd, okrt_render_data* dst);
 void launchAccumulate(hipStream_t stream, const okrt_render_data& rd, uint32_t pixels, uint32_t frames, const float4* radiance, float4* accum,
                       uint32_t* result);

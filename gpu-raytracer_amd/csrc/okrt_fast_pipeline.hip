@@ -103,7 +103,11 @@ struct FastScene {
         okrt_render_data* rdDev = nullptr;  // RenderData of the launch set in flight, for the fused camera kernel
         float4* radiance = nullptr;  // per-frame radiance slots when several frames share one launch set
         size_t radianceCap = 0;
+        uint32_t* tileOrder = nullptr;  // camera tiles of this set, longest first (okrt_fast_shade.hip: orderTilesKernel)
+        size_t tileOrderCap = 0;
     } slot[kPipelineSlots];
+    uint32_t* tileCost = nullptr;  // steps every camera tile took in frame 0 of the most recent set (shared by the slots: a property of scene + camera)
+    size_t tileCostCap = 0;
     uint32_t overflowCap = 0;  // entries per thread the spill slabs need for the current tree
     int traceBlocks = 0, cus = 0;
     // which algorithm traces the camera segment: decided once per structure from a probe of the first frame (probeCameraSegment)
@@ -265,12 +269,13 @@ void fastDestroy(FastScene* fs) {
     fs->tris.release();
     if (fs->builder) deviceBuilderDestroy(fs->builder);
     for (FastScene::LaunchSlot& ls : fs->slot) {
-        for (void* p : {(void*)ls.rdDev, (void*)ls.counts, (void*)ls.overflow, (void*)ls.hb.h, (void*)ls.hb.tri, (void*)ls.radiance})
+        for (void* p : {(void*)ls.rdDev, (void*)ls.counts, (void*)ls.overflow, (void*)ls.hb.h, (void*)ls.hb.tri, (void*)ls.radiance, (void*)ls.tileOrder})
             if (p) hipFree(p);
         for (RayQueue& q : ls.q)
             for (void* p : {(void*)q.a, (void*)q.b, (void*)q.c, (void*)q.d})
                 if (p) hipFree(p);
     }
+    if (fs->tileCost) hipFree(fs->tileCost);
     delete fs;
 }
 
@@ -388,7 +393,9 @@ LaunchStatus ensureQueues(FastScene& fs, FastScene::LaunchSlot& ls, const SceneV
     }
     const FailAllocScope failScope;
     qp.total = qp.perFrame * frames;
-    qp.cap = (((qp.total + kShards - 1) / kShards + 255) / 256) * 256;
+    // a shard holds every 8th tile (by cost rank) with all its frames: ceil(tiles / 8) x frames x 64 positions, >= total / 8
+    const uint32_t tilesPerFrame = qp.perFrame >> 6;
+    qp.cap = ((((tilesPerFrame + kShards - 1) / kShards) * frames * 64u + 255u) / 256u) * 256u;
     qp.items = (size_t)qp.cap * kShards;
     const size_t items = qp.items;
     // Queue 1 (56 B per item) and the hit records (20 B) are always needed. Queue 0 only exists when something uses it:
@@ -438,6 +445,22 @@ LaunchStatus ensureQueues(FastScene& fs, FastScene::LaunchSlot& ls, const SceneV
     if (qp.lastBounce + 2 > kMaxSegments) {
         err = "max_bounces too large for the fast pipeline";
         return LaunchStatus::Invalid;
+    }
+    if (tilesPerFrame > ls.tileOrderCap) {
+        hipStreamSynchronize(stream);
+        ls.tileOrderCap = 0;
+        if (!devAlloc(&ls.tileOrder, 2 * (size_t)tilesPerFrame, err)) return LaunchStatus::OutOfMemory;  // the order + the sort's keys
+        ls.tileOrderCap = tilesPerFrame;
+    }
+    if (tilesPerFrame != fs.tileCostCap) {  // another tile size: the recorded costs belong to other tiles (rare: resize / set_tile)
+        hipDeviceSynchronize();               // (other slots' streams may still read the old array)
+        fs.tileCostCap = 0;
+        if (!devAlloc(&fs.tileCost, tilesPerFrame, err)) return LaunchStatus::OutOfMemory;
+        if (hipMemsetAsync(fs.tileCost, 0, (size_t)tilesPerFrame * sizeof(uint32_t), stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            err = "hipMemsetAsync(tile costs)";
+            return LaunchStatus::Device;
+        }
+        fs.tileCostCap = tilesPerFrame;
     }
     if (!ls.rdDev && !devAlloc(&ls.rdDev, 1, err)) return LaunchStatus::OutOfMemory;
     if (!ls.counts && !devAlloc(&ls.counts, kAllCountWords, err)) return LaunchStatus::OutOfMemory;
@@ -503,7 +526,14 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     // the kernel that appends its rays settles the hits in advance, traceKernel stores hit-or-miss, missKernel shades the misses.
     const bool terminal = s.lastSegmentDark && lastBounce >= 1 && radiance != nullptr && !cnt;
     const int terminalMode = s.lastSegmentAnyHit ? 2 : 1;
-    const FusedArgs fa{perFrame, ls.q[1], ls.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, ls.rdDev, (terminal && lastBounce == 1) ? 1u : 0u};
+    // camera tiles longest first (fused packet kernel only; OKRT_FAST_LPT=0 keeps the frame-major order)
+    static const bool envLpt = !getenv("OKRT_FAST_LPT") || atoi(getenv("OKRT_FAST_LPT")) != 0;
+    const bool lpt = envLpt && packet && envFused;
+    const uint32_t tilesPerFrame = perFrame >> 6;
+    if (lpt) launchOrderTiles(stream, fs.tileCost, tilesPerFrame, frames, ls.tileOrder, ls.tileOrder + tilesPerFrame, ls.counts);
+    const FusedArgs fa{perFrame, ls.q[1], ls.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, ls.rdDev, (terminal && lastBounce == 1) ? 1u : 0u,
+                       lpt ? ls.tileOrder : nullptr, lpt ? fs.tileCost : nullptr, frames};
+    const ShardView cameraShards = lpt ? ShardView{cap, 0u, envBatch, envAffinity, ls.counts, ls.counts + kCursorBase} : shards(0, true);
     const uint32_t pixels32 = (uint32_t)pixels;
     // the one step of a launch set that touches the accumulation: after the previous set's (another stream may carry it)
     auto orderedAccumulate = [&]() {
@@ -513,7 +543,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     };
     if (packet && envFused) {
         // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
-        launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, shards(0, true), frames, counters, rayTotals, fa);
+        launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, cameraShards, frames, counters, rayTotals, fa);
         mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
     } else {
         // segment 0 as three kernels: camera rays into q[0] (a, b only), trace, shade

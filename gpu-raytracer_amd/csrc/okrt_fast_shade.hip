@@ -133,6 +133,39 @@ __global__ __launch_bounds__(256) void accumulateKernel(okrt_render_data rd, uin
     result[p] = toUnorm8(a.x / n) | (toUnorm8(a.y / n) << 8) | (toUnorm8(a.z / n) << 16) | (toUnorm8(a.w / n) << 24);
 }
 
+// Camera tiles, longest first. A launch set's tail is its longest dependent chain: the Sponza-class frame has tiles of 275
+// traversal steps among an average of 25, and one of those reserved last keeps the camera kernel alive for ~0.15 ms on an
+// emptied GPU — a fifth of a rank's whole region in an 8-way split. The same tile costs the same in the next frame, so every set
+// records the steps of its frame-0 tiles and the next set issues its tiles in descending order of that (one block: counting sort
+// by min(steps, 1023), any order inside a bucket). order[r] = tile of rank r; shard s of the camera queue then walks ranks s,
+// s + 8, ... (a stratified share of every cost class per XCD), all frames of a tile in a row. Which tile is traced when changes
+// nothing in the picture (radiance goes to the pixel's own slot).
+// (tileCost may be rewritten by another slot's camera kernel while this runs — sets in flight share it — so every cost is read
+// ONCE, into `keys`: both passes of the sort must see the same bucket for a tile or the result is no permutation.)
+__global__ __launch_bounds__(1024) void orderTilesKernel(const uint32_t* tileCost, uint32_t tiles, uint32_t frames, uint32_t* __restrict__ order,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ shardCounts) {
+    __shared__ uint32_t hist[1024], start[1024];
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += 1024) {
+        const uint32_t b = 1023u - min(__hip_atomic_load(&tileCost[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1023u);  // bucket 0 = the most expensive
+        keys[t] = b;
+        atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < 1024; ++b) {
+            start[b] = acc;
+            acc += hist[b];
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += 1024) order[atomicAdd(&start[keys[t]], 1u)] = t;
+    if (tid < kShards) shardCounts[tid * kCursorStride] = ((tiles + kShards - 1u - tid) / kShards) * frames * 64u;  // ranks tid, tid + 8, ...
+}
+
 // RenderData from the kernel-argument segment into device memory (what the fused camera kernel reads).
 __global__ __launch_bounds__(64) void setRenderDataKernel(okrt_render_data rd, okrt_render_data* dst) {
     static_assert(sizeof(okrt_render_data) == 60 * sizeof(uint32_t), "RenderData is 60 words");
@@ -140,6 +173,10 @@ __global__ __launch_bounds__(64) void setRenderDataKernel(okrt_render_data rd, o
 }
 
 }  // namespace
+
+void launchOrderTiles(hipStream_t stream, const uint32_t* tileCost, uint32_t tiles, uint32_t frames, uint32_t* order, uint32_t* keys, uint32_t* shardCounts) {
+    hipLaunchKernelGGL(orderTilesKernel, dim3(1), dim3(1024), 0, stream, tileCost, tiles, frames, order, keys, shardCounts);
+}
 
 void launchSetRenderData(hipStream_t stream, const okrt_render_data& rd, okrt_render_data* dst) {
     hipLaunchKernelGGL(setRenderDataKernel, dim3(1), dim3(64), 0, stream, rd, dst);

@@ -454,8 +454,22 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
         }
         Ray ray;
         uint32_t seed = 0, pix = kInvalid;
+        uint32_t costTile = kInvalid;  // wave-uniform: the tile whose step count this wave records (frame 0 of the set), else kInvalid
         if (FUSED) {  // generateKernel's work: position -> (frame, pixel) -> camera ray
-            const uint32_t f = mine / fa.perFrame, ii = mine - f * fa.perFrame;
+            uint32_t f, ii;
+            if (fa.tileOrder) {
+                // longest tiles first (okrt_fast_pipeline.hip: "camera tiles, longest first"): shard s holds the tiles of cost rank
+                // s, s + 8, s + 16, ... in that order, all frames of a tile next to each other
+                const uint32_t s_ = base / sv.cap, u = (base - s_ * sv.cap) >> 6;
+                const uint32_t rk = u / fa.frames;
+                f = u - rk * fa.frames;
+                const uint32_t tileIdx = fa.tileOrder[rk * kShards + s_];
+                ii = (tileIdx << 6) + lane;
+                if (f == 0u) costTile = tileIdx;
+            } else {
+                f = mine / fa.perFrame;
+                ii = mine - f * fa.perFrame;
+            }
             uint32_t px, lrow;
             ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
             if (primaryPixel(tile, ii, px, lrow)) {
@@ -487,6 +501,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
             }
 
         uint32_t sp = 0, cur = 0;  // wave-uniform
+        uint32_t tileCostSteps = 0;  // wave-uniform: node steps + triangle tests of this tile
 #ifdef OKRT_ITER_HIST
         uint32_t tileSteps = 0;
 #endif
@@ -503,6 +518,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 const uint4* np = nodes + (size_t)cur * 4;  // uniform address: scalar loads
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 if (COUNT) nNodes++;
+                if (FUSED) tileCostSteps++;
 #ifdef OKRT_ITER_HIST
                 tileSteps++;
 #endif
@@ -551,6 +567,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 }
             } else {
                 const uint32_t count = ((cur >> 27) & 15u) + 1u;
+                if (FUSED) tileCostSteps += count;
 #ifdef OKRT_STAMPS
                 pLeafTris += count;
 #endif
@@ -594,6 +611,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 stStream(&hb.tri[mine], hitTri);
             }
         } else {  // shadeKernel<FIRST>'s work on the hits this wave holds in registers
+            if (fa.tileCost && costTile != kInvalid && lane == 0) fa.tileCost[costTile] = tileCostSteps;  // what the next set orders its tiles by
             bool alive = false;
             V3 contribution = mk(1.f, 1.f, 1.f), light = mk(0.f, 0.f, 0.f);
             if (valid) {

@@ -2,6 +2,7 @@
 there), plus the boundary's error behaviour and edge cases."""
 import ctypes as C
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -376,18 +377,24 @@ def test_launch_sets_shrink_when_the_allocator_says_no():
 
 
 def test_interval_ms_only_sums_launch_sets_of_the_newest_shape():
-    """okrt_get_interval_ms: 100 frames = 64 + 36, on a frame this small issued as sub-sets of 32, 32, 18 and 18; the 18-frame
-    shape is the newest, so exactly those two launches are reported (a mixed sum would describe a fictitious 25-frame launch)."""
+    """okrt_get_interval_ms: 100 frames = a set of 64 and a set of 36; the 36-frame shape is the newest, so exactly that launch is
+    reported (a mixed sum would describe a fictitious 50-frame launch). With sub-sets (OKRT_PIPELINE_SPLIT_PARTS=2) a frame this
+    small is issued as 32, 32, 18 and 18 and the two 18-frame launches are."""
     desc = scenes.small_mesh_scene(seed=4, n_objects=4, detail=6)
-    rt, sc, res = scenes.instantiate(desc, 128, 72)
-    rt.ctx.set_option(abi.OPT_TIMING, 16)
-    rt.renderFrames(100)
-    ms, launches, frames = rt.ctx.interval_ms()
-    assert (launches, frames) == (2, 36) and len(ms) == 4 and all(m >= 0 for m in ms)
-    rt.renderFrames(64)
-    ms, launches, frames = rt.ctx.interval_ms()
-    assert (launches, frames) == (4, 128)
-    rt.close()
+    for parts, newest, after in (("1", (1, 36), (2, 128)), ("2", (2, 36), (4, 128))):
+        os.environ["OKRT_PIPELINE_SPLIT_PARTS"] = parts
+        try:
+            rt, sc, res = scenes.instantiate(desc, 128, 72)
+        finally:
+            del os.environ["OKRT_PIPELINE_SPLIT_PARTS"]
+        rt.ctx.set_option(abi.OPT_TIMING, 16)
+        rt.renderFrames(100)
+        ms, launches, frames = rt.ctx.interval_ms()
+        assert (launches, frames) == newest and len(ms) == 4 and all(m >= 0 for m in ms), (parts, launches, frames)
+        rt.renderFrames(64)
+        ms, launches, frames = rt.ctx.interval_ms()
+        assert (launches, frames) == after, (parts, launches, frames)
+        rt.close()
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -511,9 +518,11 @@ def test_peek_between_pipelined_launch_sets_is_never_torn():
     rt.close()
 
 
-def test_sub_sets_of_a_small_tile_are_bit_identical_to_one_set():
-    """okrt_render_frames on a small tile (one rank's stripes) issues a launch set as two sub-sets on the pipeline slots
-    (csrc/okrt_launch_plan.h); framebuffers are the ones a single set — and single frames — produce, bit for bit."""
+def test_sub_sets_of_a_small_tile_are_bit_identical_to_one_set(monkeypatch):
+    """okrt_render_frames on a small tile (one rank's stripes) can issue a launch set as two sub-sets on the pipeline slots
+    (csrc/okrt_launch_plan.h; OKRT_PIPELINE_SPLIT_PARTS=2 — the default until round 5 ordered the camera tiles longest first);
+    framebuffers are the ones a single set — and single frames — produce, bit for bit."""
+    monkeypatch.setenv("OKRT_PIPELINE_SPLIT_PARTS", "2")
     desc = scenes.small_mesh_scene(seed=9, n_objects=6, detail=9, with_lights=True)
 
     def run(pipeline, chunks):
@@ -607,7 +616,7 @@ def test_a_deferring_render_reports_the_allocator_refusal_itself():
         rt.render()
     rt.ctx.synchronize()
     _, launches, frames = rt.ctx.interval_ms()
-    assert (launches, frames) == (4, 16)  # the remembered limit: sets of 8, each issued as two sub-sets of 4 on this small frame
+    assert (launches, frames) == (2, 16)  # the remembered limit: sets of 8 (two sub-sets of 4 each under OKRT_PIPELINE_SPLIT_PARTS=2)
     rt.close()
 
 
@@ -653,7 +662,7 @@ def test_a_granted_reservation_leaves_larger_launch_sets_alone():
     rt.ctx.set_option(abi.OPT_TIMING, 8)
     rt.renderFrames(64)
     _, launches, frames = rt.ctx.interval_ms()
-    assert (launches, frames) == (2, 64)  # one set of 64 frames; on a frame this small it is issued as two sub-sets of 32
+    assert (launches, frames) == (1, 64)  # one set of 64 frames (two sub-sets of 32 on a frame this small under OKRT_PIPELINE_SPLIT_PARTS=2)
     rt.ctx.set_option(abi.OPT_PIPELINE, 0)
     rt.ctx.set_option(abi.OPT_TIMING, 8)
     rt.renderFrames(64)

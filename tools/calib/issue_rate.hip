@@ -28,6 +28,9 @@ __global__ __launch_bounds__(1024) void issueKernel(uint32_t trips, unsigned lon
     const float m = 1.0000001f, c = 1e-9f;
     uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
     unsigned long long mask = 0x5555AAAA3333CCCCull ^ blockIdx.x, m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+    const f2 pm = {m, m}, pc = {c, c};
     if (KIND == 1 || KIND == 10) asm volatile("s_mov_b64 vcc, %0" : : "s"(mask) : "vcc");
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (uint32_t t = 0; t < trips; ++t) {
@@ -73,6 +76,25 @@ __global__ __launch_bounds__(1024) void issueKernel(uint32_t trips, unsigned lon
                 asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %4, %1, %8, vcc\n v_cndmask_b32 %5, %2, %8, vcc\n v_cndmask_b32 %6, %3, %8, vcc\n"
                              "v_cmp_gt_f32 vcc, %1, %8\n v_cndmask_b32 %7, %0, %8, vcc\n v_cndmask_b32 %4, %2, %8, vcc\n v_cndmask_b32 %5, %3, %8, vcc"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");
+            } else if (KIND >= 20 && KIND < 40) {
+#define OKRT_OP8(op, tail) asm volatile(op " %0, %0, " tail "\n " op " %1, %1, " tail "\n " op " %2, %2, " tail "\n " op " %3, %3, " tail "\n " \
+                                        op " %4, %4, " tail "\n " op " %5, %5, " tail "\n " op " %6, %6, " tail "\n " op " %7, %7, " tail \
+                                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c))
+                if (KIND == 20) OKRT_OP8("v_mul_f32", "%8");
+                else if (KIND == 21) OKRT_OP8("v_add_f32", "%8");
+                else if (KIND == 22) OKRT_OP8("v_sub_f32", "%8");
+                else if (KIND == 23) OKRT_OP8("v_fmac_f32", "%8");
+                else if (KIND == 24) OKRT_OP8("v_max3_f32", "%8, %9");
+                else if (KIND == 25) OKRT_OP8("v_and_b32", "%8");
+                else if (KIND == 26) OKRT_OP8("v_add_u32", "%8");
+                else if (KIND == 27) OKRT_OP8("v_lshlrev_b32", "%8");
+                else if (KIND == 28) OKRT_OP8("v_med3_f32", "%8, %9");
+                else if (KIND == 29) OKRT_OP8("v_bfe_u32", "8, 8");
+#undef OKRT_OP8
+            } else if (KIND == 40) {  // packed fp32: two FMAs per lane and instruction
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm), "v"(pc));
             } else if (KIND == 9) {  // the same swap on packed keys: v_min_u32 / v_max_u32 (a key-value sort with the value in the key's low bits)
                 asm volatile("v_min_u32 %4, %0, %1\n v_max_u32 %5, %0, %1\n v_min_u32 %6, %2, %3\n v_max_u32 %7, %2, %3\n"
                              "v_min_u32 %0, %4, %6\n v_max_u32 %1, %4, %6\n v_min_u32 %2, %5, %7\n v_max_u32 %3, %5, %7"
@@ -89,7 +111,7 @@ __global__ __launch_bounds__(1024) void issueKernel(uint32_t trips, unsigned lon
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
-    const float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 ^ s1 ^ s2 ^ s3) + (float)(m0 ^ m1 ^ m2 ^ m3);
+    const float r = p0.x + p1.y + p2.x + p3.y + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 ^ s1 ^ s2 ^ s3) + (float)(m0 ^ m1 ^ m2 ^ m3);
     if (r == 1.2345e-30f) sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -142,6 +164,17 @@ int main() {
     measure<8>("cswap", 10.0 / 8.0, cus, dCycles, sink);
     measure<9>("minmax_u", 1, cus, dCycles, sink);
     measure<2>("minmax", 1, cus, dCycles, sink);
+    measure<20>("mul_f32", 1, cus, dCycles, sink);
+    measure<21>("add_f32", 1, cus, dCycles, sink);
+    measure<22>("sub_f32", 1, cus, dCycles, sink);
+    measure<23>("fmac_f32", 1, cus, dCycles, sink);
+    measure<40>("pk_fma", 1, cus, dCycles, sink);
+    measure<24>("max3_f32", 1, cus, dCycles, sink);
+    measure<28>("med3_f32", 1, cus, dCycles, sink);
+    measure<25>("and_b32", 1, cus, dCycles, sink);
+    measure<26>("add_u32", 1, cus, dCycles, sink);
+    measure<27>("lshlrev", 1, cus, dCycles, sink);
+    measure<29>("bfe_u32", 1, cus, dCycles, sink);
     measure<3>("cvt", 1, cus, dCycles, sink);
     measure<4>("salu", 1, cus, dCycles, sink);
     measure<5>("fma+salu", 2, cus, dCycles, sink);
