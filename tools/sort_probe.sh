@@ -1,5 +1,6 @@
 #!/bin/bash
-# what ray coherence is worth to traceKernel: the bounce-ray queue fully sorted (OKRT_FAST_SORT, csrc/okrt_fast_sort.hip) against the append order
+# what ray coherence is worth to traceKernel: the bounce-ray queue fully sorted (OKRT_FAST_SORT) against the append order.
+# The diagnostic is no longer in the product: `git apply tools/experiments/r04_ray_sort_probe.diff` first (round-4 tree shape).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/sort
 for mode in 0 1 2 3 4; do
   echo "== OKRT_FAST_SORT=$mode"
