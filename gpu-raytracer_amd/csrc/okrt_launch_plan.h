@@ -1,6 +1,6 @@
 // okrt_launch_plan.h — how many frames the next launch set of a progressive accumulation traces, and whether it rides the
 // pipeline slots (okrt_context.hip: renderBatched / the deferred-render reservation). Plain arithmetic, no HIP: the same
-// functions answer okrt_debug_launch_plan, which the CPU tests call (tests/test_abi.py).
+// functions answer okrt_debug_launch_plan, which the CPU tests call (tests/test_launch_plan.py).
 #pragma once
 #include <algorithm>
 #include <cstdint>
