@@ -669,3 +669,39 @@ def test_a_granted_reservation_leaves_larger_launch_sets_alone():
     _, launches, frames = rt.ctx.interval_ms()
     assert (launches, frames) == (1, 64)
     rt.close()
+
+
+def test_longest_first_tile_order_leaves_the_picture_alone(tmp_path):
+    """Round 5: the fused camera kernel issues its 8x8 tiles in descending order of the steps they took in the previous launch set
+    (okrt_fast_shade.hip: orderTilesKernel). The order is read from the environment once per process (OKRT_FAST_LPT), so the two
+    pictures come from two processes: accumulation and resolve after a mix of launch shapes must be the same bytes, through a
+    striped tile as well (a rank's share: the shards are short there)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, importlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "scenes = importlib.import_module('gpu-raytracer_amd.scenes'); abi = importlib.import_module('gpu-raytracer_amd._abi')\n"
+        "out = []\n"
+        "for tile in (None, (8, 1, 3)):\n"
+        "    rt, _, _ = scenes.instantiate(scenes.small_mesh_scene(seed=11, n_objects=6, detail=9), 320, 200)\n"
+        "    if tile: rt.ctx.set_tile(*tile)\n"
+        "    for m in (1, 7, 1, 1, 20, 3):\n"
+        "        rt.renderFrames(m)\n"
+        "    for _ in range(9): rt.render()\n"
+        "    out += [rt.ctx.read_accum(), rt.ctx.read_result().astype(np.float32)]\n"
+        "    rt.close()\n"
+        "np.savez(sys.argv[1], *out)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for lpt in ("1", "0"):
+        path = str(tmp_path / f"lpt{lpt}.npz")
+        env = dict(os.environ, OKRT_FAST_LPT=lpt)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        files.append(np.load(path))
+    a, b = files
+    assert len(a.files) == 4
+    for k in a.files:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert (a["arr_0"][..., 3] == 42).all()

@@ -19,6 +19,10 @@ for c in range(cases):
     W, H = int(rng.integers(17, 200)), int(rng.integers(9, 120))
     mb, frames = int(rng.integers(0, 5)), int(rng.integers(1, 4))
     desc = scenes.small_mesh_scene(**kw)
+    dark = bool(rng.integers(0, 2))  # round 5: half of the cases without the emitter, so that scenes without lights take the last-segment shortcut
+    if dark:
+        for e in desc.entities:
+            e.material = {k: v for k, v in e.material.items() if k not in ("emissionColour", "emissionPower")}
     ort, _, _ = oracle.instantiate(desc, W, H)
     ort.ctx.set_option(abi.OPT_MAX_BOUNCES, mb)
     for _ in range(frames): ort.render()
@@ -33,7 +37,7 @@ for c in range(cases):
             for _ in range(frames): rt.render()
         ga = rt.ctx.read_accum()
         frac, rmse, nanmm, _ = compare_accum(ga, ca, frames)
-        tag = f"case {c} {kw} {W}x{H} mb={mb} frames={frames} trav={trav} builder={builder}"
+        tag = f"case {c} {kw} dark={dark} {W}x{H} mb={mb} frames={frames} trav={trav} builder={builder}"
         if frac < worst[0]: worst = (frac, rmse, tag)
         lim = 0.97 if (kw["transforms"] or frames > 1 or mb > 1) else 0.99
         if frac < lim or rmse > 0.05 or not (ga[..., 3] == frames).all():
