@@ -234,7 +234,7 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         term1 = terminal and mb == 1
         cam_alg = (56 + (16 if term1 else 0)) * cam_surv + slot * max(pixels - cam_surv, 0) + 64 * cam_hits + 16 * cam_taps + 16 * cam_env
         cam_l2 = (64 * cam_nodes + 48 * cam_tris) / 64 + cam_alg
-        if build["flags"] & 8:  # OKRT_BUILD_FLAG_CAMERA_PER_RAY: the probe chose the per-ray kernel (three launches, queue 0 and hit records in between)
+        if build.get("flags", 0) & 8:  # OKRT_BUILD_FLAG_CAMERA_PER_RAY: the probe chose the per-ray kernel (three launches, queue 0 and hit records in between)
             cam_alg += (32 + 32 + 20 + 20 + 32) * pixels  # generate writes 32 B per ray, traceKernel reads them + writes 20, shadeKernel<FIRST> reads 32 + 20
             add("traceKernelCamera + generateKernel + shadeKernel<FIRST> (camera segment traced per ray: chosen by the probe for this scene)",
                 interval_ms[0] + interval_ms[1], cam_alg, 64 * cam_nodes + 48 * cam_tris + cam_alg, structure_bytes, (32 + 32 + 20) * pixels)
@@ -331,7 +331,7 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         "node4q_visits_per_bounce_ray": round(b_nodes / max(bounce_rays, 1), 2), "tri48_tests_per_bounce_ray": round(b_tris / max(bounce_rays, 1), 2),
         # (wave-level counts under the packet kernel; under the per-ray camera kernel the same expression is the average per RAY)
         "node4q_steps_per_camera_tile": round(cam_nodes / 64 / max(pixels / 64, 1), 2), "tri48_tests_per_camera_tile": round(cam_tris / 64 / max(pixels / 64, 1), 2),
-        "camera_segment": "per ray (probe)" if build["flags"] & 8 else "8x8 packets",
+        "camera_segment": "per ray (probe)" if build.get("flags", 0) & 8 else "8x8 packets",
         "structure_bytes": structure_bytes,
         "traversal_ms_per_frame": round(trace_ms_frame, 4), "later_shading_ms_per_frame": round(shade_ms_frame, 4), "other_ms_per_frame": round(other_ms_frame, 4),
         # SURVEY.md §8d to the letter, kept under its own name: the bytes the REFERENCE's octree -> mesh -> BVH order would touch

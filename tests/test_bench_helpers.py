@@ -73,3 +73,19 @@ def test_roofline_report_is_a_fraction_and_names_its_basis(monkeypatch):
     # measured L1 -> L2 read requests (128-byte lines): as a share of the L2 peak and of the rate a pure gather sustains
     assert abs(rep["l2_frac"] - 893e6 * 128 / 17.5e-3 / 34.5e12) < 1e-3 and abs(rep["gather_ceiling_frac"] - 893e6 / 17.5e-3 / bench.gather_ceiling(0.845)) < 1e-3
     assert bench.gather_ceiling(1.0) == bench.GATHER_L2_HIT_REQUESTS_PER_S and abs(bench.gather_ceiling(0.0) - bench.GATHER_L2_MISS_REQUESTS_PER_S) < 1
+    # round 5: the last-segment shortcut changes the kernels' names and algorithmic bytes (hit-or-miss record: 32 B per ray + 4 per
+    # miss), the PMC file's issue fractions travel into the line and name what binds each kernel
+    pmc = {"kernels": {"traceKernel": {"hbm_bytes_per_launch": 8.0e9, "l2_hit_pct": 88.9, "valu_lane_util": 0.568, "l2_read_requests_per_launch": 890e6,
+                                       "valu_issue_frac": 1.19, "salu_issue_frac": 0.52, "wait_any_share": 0.46, "wait_inst_share": 0.25},
+                       "missKernel": {"hbm_bytes_per_launch": 6.5e9, "l2_hit_pct": 19.4, "valu_lane_util": 0.33, "valu_issue_frac": 0.36}}}
+    monkeypatch.setattr(bench, "load_pmc", lambda w, f: (("r99_pmc_sponza_f64.json", pmc), None))
+    rep = bench.roofline_report(args, 1, False, [12.7, 0.01, 17.5, 1.6], 1, 64, dict(build, flags=4), ref, fast, cam, 117.9e9, 1e9, 0.47, 0.095, 0.0, True)
+    names = [k["kernel"].split(" ")[0] for k in rep["kernels"]]
+    assert names == ["tracePacketKernel<FUSED>", "traceKernel<MODE", "missKernel"], names
+    tk = rep["kernels"][1]
+    bounce = rays - px
+    assert tk["algorithmic_bytes_per_launch"] == int((32 * bounce + 4 * (90_000 - 43_000)) * 64 + 64 * 65_500 + 48 * 262_267)
+    assert tk["bound"] == "valu-issue" and tk["valu_issue_frac"] == 1.19 and tk["wait_mem_share"] == 0.46 and rep["binding_resource"] == "valu-issue"
+    assert rep["kernels"][2]["bound"].startswith("fabric") and rep["bound"] == "hbm" and rep["camera_segment"] == "8x8 packets"
+    rep = bench.roofline_report(args, 1, False, [12.7, 0.01, 17.5, 1.6], 1, 64, dict(build, flags=4 | 8), ref, fast, cam, 117.9e9, 1e9, 0.47, 0.095, 0.0, True)
+    assert rep["kernels"][0]["kernel"].startswith("traceKernelCamera") and rep["camera_segment"] == "per ray (probe)"
