@@ -90,6 +90,10 @@ __global__ __launch_bounds__(1024) void issueKernel(uint32_t trips, unsigned lon
                 else if (KIND == 27) OKRT_OP8("v_lshlrev_b32", "%8");
                 else if (KIND == 28) OKRT_OP8("v_med3_f32", "%8, %9");
                 else if (KIND == 29) OKRT_OP8("v_bfe_u32", "8, 8");
+                else if (KIND == 30) OKRT_OP8("v_mul_lo_u32", "%8");
+                else if (KIND == 31) OKRT_OP8("v_mul_u32_u24", "%8");
+                else if (KIND == 32) OKRT_OP8("v_xor_b32", "%8");
+                else if (KIND == 33) OKRT_OP8("v_lshrrev_b32", "%8");
 #undef OKRT_OP8
             } else if (KIND == 40) {  // packed fp32: two FMAs per lane and instruction
                 asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
@@ -175,6 +179,10 @@ int main() {
     measure<26>("add_u32", 1, cus, dCycles, sink);
     measure<27>("lshlrev", 1, cus, dCycles, sink);
     measure<29>("bfe_u32", 1, cus, dCycles, sink);
+    measure<30>("mul_lo_u32", 1, cus, dCycles, sink);
+    measure<31>("mul_u24", 1, cus, dCycles, sink);
+    measure<32>("xor_b32", 1, cus, dCycles, sink);
+    measure<33>("lshrrev", 1, cus, dCycles, sink);
     measure<3>("cvt", 1, cus, dCycles, sink);
     measure<4>("salu", 1, cus, dCycles, sink);
     measure<5>("fma+salu", 2, cus, dCycles, sink);
