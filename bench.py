@@ -529,6 +529,9 @@ def main():
     # every slot allocates its queues on first use — 2.6 ms per rank inside a 1.7 ms region when this was missing (r04 N = 8 rehearsal)
     k_here = args.steps // world if (world > 1 and args.split == "samples") else args.steps
     shape_warm = k_here if k_here <= fpl else fpl + k_here % fpl
+    # (the per-kernel event ring is switched on BEFORE these rehearsals: its events are created on a slot's first use, and the first
+    # timed region used to pay for that — it read 1-8 % above its four repeats, the more the smaller the rank's tile)
+    ctx.set_option(abi.OPT_TIMING, min(5 * args.steps, 4096))
     for _ in range(2):
         run_frames(shape_warm, False)
     if world > 1 and not samples_split:
