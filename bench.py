@@ -286,7 +286,8 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                 # issue-rate roofline (tools/pmc_traffic.py pass sq2; ceilings measured by tools/calib/issue_rate.hip -> profiles/r05_issue_rate.txt:
                 # a SIMD starts at most ONE vector instruction per quad-cycle — min / max / select / compare / convert all measure 0.96-0.98, only
                 # v_fma_f32 dual-rates to 1.55-1.77 — and one scalar instruction beside it): instructions of the kind / (SIMDs x kernel quad-cycles)
-                for key in ("valu_issue_frac", "valu_busy_frac", "salu_issue_frac", "scalar_busy_frac", "vmem_issue_frac", "lds_issue_frac"):
+                # valu_slot_frac (pass sq3) prices the same stream with its measured MIX: slots needed at the per-kind rates / slots the kernel had
+                for key in ("valu_issue_frac", "valu_slot_frac", "valu_slot_frac_lower", "valu_dual_rate_share", "valu_busy_frac", "salu_issue_frac", "scalar_busy_frac", "vmem_issue_frac", "lds_issue_frac"):
                     if m.get(key) is not None:
                         k[key] = m[key]
                 if m.get("wait_any_share") is not None:
@@ -305,7 +306,7 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
                         k["gather_ceiling_frac"] = round(per_s / gather_ceiling(m["l2_hit_pct"] / 100.0), 4)
         traffic, lane_util, l2_hit = head.get("traffic"), head.get("valu_lane_util"), head.get("l2_hit_pct")
         for k in kernels:  # what binds each kernel, from its own measured fractions (the largest one names it)
-            cands = {"valu-issue": k.get("valu_issue_frac") or 0.0, "gather (L1 -> L2 request rate of the memory hierarchy)": k.get("gather_ceiling_frac") or 0.0,
+            cands = {"valu-issue": min(k.get("valu_slot_frac") or k.get("valu_issue_frac") or 0.0, 1.0), "gather (L1 -> L2 request rate of the memory hierarchy)": k.get("gather_ceiling_frac") or 0.0,
                      "fabric (L2 <-> Infinity Cache / HBM bytes)": k.get("traffic_frac") or 0.0}
             best = max(cands, key=lambda n: cands[n])
             k["bound"] = best if cands[best] >= 0.5 else "latency (no resource above half of its ceiling: short dependent launches)"
@@ -324,7 +325,10 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "algorithmic_frac": head["algorithmic_frac"],
         "l2_frac": head["l2_frac"], "gather_ceiling_frac": head["gather_ceiling_frac"], "l2_hit_pct": l2_hit, "valu_lane_util": lane_util,
         # the dominant kernel's binding resource (kernels[].bound): `bound` above stays the HBM roofline the contract asks for
-        "binding_resource": head.get("bound"), "valu_issue_frac": head.get("valu_issue_frac"), "salu_issue_frac": head.get("salu_issue_frac"),
+        "binding_resource": head.get("bound"), "valu_issue_frac": head.get("valu_issue_frac"),
+        # the vector port's occupancy priced with the kernel's measured instruction mix, [lower, upper] (tools/pmc_traffic.py pass sq3): full when it brackets 1
+        "valu_slot_frac_range": [head.get("valu_slot_frac_lower"), head.get("valu_slot_frac")] if head.get("valu_slot_frac") is not None else None,
+        "salu_issue_frac": head.get("salu_issue_frac"),
         "issue_ceiling": "one VALU instruction per SIMD quad-cycle (measured 0.96-0.98 for min / max / select / compare / convert; v_fma_f32 alone 1.55-1.77) "
                          "and one SALU instruction beside it: tools/calib/issue_rate.hip -> profiles/r05_issue_rate.txt",
         "kernels": kernels,

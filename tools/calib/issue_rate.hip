@@ -95,6 +95,9 @@ __global__ __launch_bounds__(1024) void issueKernel(uint32_t trips, unsigned lon
                 else if (KIND == 32) OKRT_OP8("v_xor_b32", "%8");
                 else if (KIND == 33) OKRT_OP8("v_lshrrev_b32", "%8");
 #undef OKRT_OP8
+            } else if (KIND == 41) {  // register moves (the compiler's phi copies: 89 of the bounce kernel's 644 static vector instructions)
+                asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
             } else if (KIND == 40) {  // packed fp32: two FMAs per lane and instruction
                 asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
                              "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5"
@@ -182,6 +185,7 @@ int main() {
     measure<30>("mul_lo_u32", 1, cus, dCycles, sink);
     measure<31>("mul_u24", 1, cus, dCycles, sink);
     measure<32>("xor_b32", 1, cus, dCycles, sink);
+    measure<41>("mov_b32", 1, cus, dCycles, sink);
     measure<33>("lshrrev", 1, cus, dCycles, sink);
     measure<3>("cvt", 1, cus, dCycles, sink);
     measure<4>("salu", 1, cus, dCycles, sink);

@@ -46,7 +46,13 @@ PASSES = [
     # and the clock: GRBM_GUI_ACTIVE = busy cycles summed over the 8 XCDs (GRBM has its own 2 slots: it rides this pass)
     ("sq2", ["--pmc", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY",
              "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace"]),
+    # the instruction MIX of the vector stream: fp32 add / mul / fma start at 1.75-1.77 per SIMD quad-cycle, everything else at 0.96-0.98
+    # (selects, compares, min / max, converts, most integer forms), transcendentals take two slots (profiles/r05_issue_rate.txt) — with the
+    # mix the port's occupancy can be priced per kernel (valu_slot_frac <= ~1) instead of read off an instruction count whose ceiling moves
+    ("sq3", ["--pmc", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT",
+             "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "--kernel-trace"]),
 ]
+DUAL_RATE = 1.76  # fp32 add / mul / fma per SIMD quad-cycle, measured (tools/calib/issue_rate.hip)
 FAMILIES = ("tracePacketKernel", "traceKernel", "shadeKernel", "missKernel", "accumulateKernel", "generateKernel", "renderReferenceOrder")
 SIMDS = 256 * 4  # MI355X: 256 CUs x 4 SIMDs
 
@@ -71,7 +77,7 @@ def main():
     ap.add_argument("--workload", default="sponza")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--out", default="gpurun_out/pmc")
-    ap.add_argument("--passes", default="stats,fetch,write,sq,l1,sq2")
+    ap.add_argument("--passes", default="stats,fetch,write,sq,l1,sq2,sq3")
     args = ap.parse_args()
     import bench
     args.out = os.path.abspath(args.out)  # rocprofv3 runs from /tmp
@@ -101,13 +107,14 @@ def main():
             if fam and not counting:
                 dur[fam].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     ctr = collections.defaultdict(lambda: collections.defaultdict(list))
-    for name in ("fetch", "write", "sq", "l1", "sq2"):
+    for name in ("fetch", "write", "sq", "l1", "sq2", "sq3"):
         for f in glob.glob(os.path.join(args.out, f"{tag}_{name}", "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 fam, counting = family(r["Kernel_Name"])
                 if fam and not counting:
                     # (SQ_INSTS_VALU rides both SQ passes: pass sq2's copy sits beside GRBM_GUI_ACTIVE, i.e. the same launches' clock)
-                    cname = r["Counter_Name"] + ("@sq2" if name == "sq2" and r["Counter_Name"] == "SQ_INSTS_VALU" else "")
+                    cname = r["Counter_Name"] + ("@" + name if name in ("sq2", "sq3") and r["Counter_Name"] in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE") and
+                                                  not (name == "sq2" and r["Counter_Name"] == "GRBM_GUI_ACTIVE") else "")
                     ctr[fam][cname].append(float(r["Counter_Value"]))
     for table in (dur, ctr):  # (see family(): MODE 0 beside MODE 1 = the per-ray camera segment; MODE 0 alone = every bounce segment)
         if "traceKernel0" in table:
@@ -162,6 +169,23 @@ def main():
             # (pass sq has no clock of its own: SQ_ACTIVE_INST_VALU is scaled by the two passes' SQ_INSTS_VALU, equal up to run-to-run noise)
             if avg.get("SQ_ACTIVE_INST_VALU") and avg.get("SQ_INSTS_VALU") and avg.get("SQ_INSTS_VALU@sq2"):
                 k["valu_busy_frac"] = round(avg["SQ_ACTIVE_INST_VALU"] * (avg["SQ_INSTS_VALU@sq2"] / avg["SQ_INSTS_VALU"]) / slots, 4)
+        gui3, tot3 = avg.get("GRBM_GUI_ACTIVE@sq3", 0.0), avg.get("SQ_INSTS_VALU@sq3", 0.0)
+        if gui3 and tot3:
+            fast = avg.get("SQ_INSTS_VALU_ADD_F32", 0.0) + avg.get("SQ_INSTS_VALU_MUL_F32", 0.0) + avg.get("SQ_INSTS_VALU_FMA_F32", 0.0)
+            trans = avg.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            other = max(tot3 - fast - trans, 0.0)
+            slots3 = SIMDS * (gui3 / 8.0 / 4.0)
+            k["valu_dual_rate_share"] = round(fast / tot3, 4)          # fp32 add / mul / fma among the vector instructions
+            k["valu_mix"] = {"fma_f32": round(avg.get("SQ_INSTS_VALU_FMA_F32", 0.0) / tot3, 4), "mul_f32": round(avg.get("SQ_INSTS_VALU_MUL_F32", 0.0) / tot3, 4),
+                             "add_f32": round(avg.get("SQ_INSTS_VALU_ADD_F32", 0.0) / tot3, 4), "trans_f32": round(trans / tot3, 4),
+                             "cvt": round(avg.get("SQ_INSTS_VALU_CVT", 0.0) / tot3, 4), "int32": round(avg.get("SQ_INSTS_VALU_INT32", 0.0) / tot3, 4)}
+            # issue slots the stream needs at the measured per-kind rates / slots the kernel had = the vector port's occupancy, as a RANGE: the
+            # counters classify fp32 add / mul / fma (dual-rate), conversions (full-rate) and transcendentals (two slots); the rest is a mix of
+            # full-rate forms (select, compare, min / max, lshl, bfe, mul_lo) and dual-rate ones (mov, and, xor, add_u32, lshr). Upper figure:
+            # the rest at one slot each; lower: the rest at the dual rate. A port is full when the range brackets 1.
+            cvt = min(avg.get("SQ_INSTS_VALU_CVT", 0.0), other)
+            k["valu_slot_frac"] = round((fast / DUAL_RATE + other / 0.97 + 2.0 * trans) / slots3, 4)
+            k["valu_slot_frac_lower"] = round(((fast + other - cvt) / DUAL_RATE + cvt / 0.97 + 2.0 * trans) / slots3, 4)
         if avg.get("TCP_TCC_READ_REQ_sum"):
             k["l2_read_requests_per_launch"] = avg["TCP_TCC_READ_REQ_sum"] * per_set  # 128-byte lines
             k["l1_accesses_per_launch"] = avg.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) * per_set
