@@ -89,3 +89,25 @@ def test_roofline_report_is_a_fraction_and_names_its_basis(monkeypatch):
     assert rep["kernels"][2]["bound"].startswith("fabric") and rep["bound"] == "hbm" and rep["camera_segment"] == "8x8 packets"
     rep = bench.roofline_report(args, 1, False, [12.7, 0.01, 17.5, 1.6], 1, 64, dict(build, flags=4 | 8), ref, fast, cam, 117.9e9, 1e9, 0.47, 0.095, 0.0, True)
     assert rep["kernels"][0]["kernel"].startswith("traceKernelCamera") and rep["camera_segment"] == "per ray (probe)"
+
+
+def test_pmc_tool_sorts_kernel_names_into_families():
+    """tools/pmc_traffic.py attributes rocprofv3 rows to kernel families by name: the counting variants are left out, the per-ray camera
+    kernel (traceKernel MODE 0 beside a MODE 1 launch) is kept apart from the bounce kernel, missKernel is a family of its own."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(REPO, "tools", "pmc_traffic.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    ns = "void okrt::fastdetail::(anonymous namespace)::"
+    assert pmc.family(ns + "traceKernel<false, 1, >(okrt::fastdetail::FastView, ...)")[0] == "traceKernel"
+    assert pmc.family(ns + "traceKernel<false, 1>(okrt::fastdetail::FastView, ...)") == ("traceKernel", False)
+    assert pmc.family(ns + "traceKernel<false, 0>(okrt::fastdetail::FastView, ...)") == ("traceKernel0", False)
+    assert pmc.family(ns + "traceKernel<true, 0>(okrt::fastdetail::FastView, ...)") == ("traceKernel0", True)
+    assert pmc.family(ns + "tracePacketKernel<false, true>(HIP_vector_type<unsigned int, 4u> const*, ...)") == ("tracePacketKernel", False)
+    assert pmc.family(ns + "tracePacketKernel<true, false>(HIP_vector_type<unsigned int, 4u> const*, ...)") == ("tracePacketKernel", True)
+    assert pmc.family(ns + "shadeKernel<false, true>(okrt::SceneView, ...)") == ("shadeKernel", True)
+    assert pmc.family("okrt::fastdetail::(anonymous namespace)::missKernel(okrt::SceneView, ...)") == ("missKernel", False)
+    assert pmc.family("okrt::fastdetail::(anonymous namespace)::orderTilesKernel(unsigned int const*, ...)") == (None, False)
+    assert pmc.family("__amd_rocclr_fillBufferAligned") == (None, False)
+    assert [n for n, _ in pmc.PASSES] == ["stats", "fetch", "write", "sq", "l1", "sq2", "sq3"]
+    assert all(len([c for c in flags if c.startswith("SQ_")]) <= 8 for _, flags in pmc.PASSES)  # 8 SQ slots per pass (MI355X_MICROARCH.md)
