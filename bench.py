@@ -754,6 +754,9 @@ def main():
         if plan["rehearsal"]:
             out["config"]["note"] = (f"REHEARSAL: {world} ranks on fewer GPUs (devices {plan['devices']}); the ranks share GPU time, so this line says "
                                      "nothing about scaling — it exercises the N-rank code path")
+        elif world > 1 and "FALLBACK" in group.transport:
+            out["config"]["note"] = ("the RCCL communicator could not be created (gather_transport has the error): the tiles were exchanged through "
+                                     "host memory, so gather_ms is not an xGMI figure; value covers the ranks' rendering only, as always")
         out["roofline"] = roofline_report(args, world, samples_split, interval_ms, interval_launches, interval_frames, build,
                                           ref_counters, fast_counters, camera_counters, ref_trav_bytes, ref_shade_bytes, trace_ms_frame,
                                           shade_ms / frames, other_ms / frames, terminal)

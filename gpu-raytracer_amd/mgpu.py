@@ -221,19 +221,35 @@ class TileGroup:
         elif plan["rehearsal"]:
             self.transport = "host memory (REHEARSAL: ranks share a GPU, RCCL cannot join them)"
         else:
+            # One RCCL communicator over all ranks. A rank that cannot join (no unique id, ncclCommInitRank refused) must not leave the
+            # others waiting: every rank reports, and if any failed ALL fall back to the host-memory exchange, which says so in
+            # `transport` (the bench line then carries a flagged gather instead of no line at all).
+            problem = ""
             ident = (C.c_uint8 * 128)()
             if plan["rank"] == 0:
                 st = fns.comm_unique_id(ident)
                 if st != 0:
-                    raise _abi.OkrtError(f"okrt_comm_unique_id: status {st}: {fns.comm_last_error(None).decode()}")
-                store.set("rccl_id", bytes(ident))
-            ident = (C.c_uint8 * 128).from_buffer_copy(store.get("rccl_id"))
+                    problem = f"okrt_comm_unique_id: status {st}: {fns.comm_last_error(None).decode()}"
+                store.set("rccl_id", b"" if problem else bytes(ident))
+            raw = store.get("rccl_id")
             comm = P()
-            st = fns.comm_create(self.h[0], ident, plan["rank"], self.world, C.byref(comm))
-            if st != 0:
-                raise _abi.OkrtError(f"okrt_comm_create: status {st}: {fns.comm_last_error(None).decode()}")
-            self.comms = [comm]
-            self.transport = fns.comm_transport(comm).decode()
+            if len(raw) != 128:
+                problem = problem or "rank 0 has no RCCL unique id"
+            else:
+                ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+                st = fns.comm_create(self.h[0], ident, plan["rank"], self.world, C.byref(comm))
+                if st != 0:
+                    problem = f"okrt_comm_create: status {st}: {fns.comm_last_error(None).decode()}"
+                    comm = P()
+            problems = [b.decode() for b in store.allgather(problem.encode())]
+            if any(problems):
+                if comm:
+                    fns.comm_destroy(comm)
+                first = next(k for k, m in enumerate(problems) if m)
+                self.transport = f"host memory (FALLBACK, not RCCL: rank {first}: {problems[first]})"
+            else:
+                self.comms = [comm]
+                self.transport = fns.comm_transport(comm).decode()
 
     @property
     def is_root(self):

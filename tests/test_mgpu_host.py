@@ -185,3 +185,64 @@ def test_bench_without_a_gpu_fails_loudly_not_silently():
         if r.returncode == 0:
             pytest.skip("a GPU is visible here: the loud-failure path cannot be exercised")
         assert "no GPU visible" in r.stderr and "torch" not in r.stderr, r.stderr[-400:]
+
+
+def test_a_rank_that_cannot_join_rccl_sends_every_rank_to_the_flagged_host_exchange(tmp_path):
+    """process_per_gpu, real devices: if ANY rank fails to create the communicator (here rank 1's okrt_comm_create), all ranks must take
+    the host-memory exchange together — the communicator rank 0 did get is destroyed again — and `transport` must say it is not RCCL."""
+    import ctypes as C
+    import threading
+    m = importlib.import_module("gpu-raytracer_amd.mgpu")
+
+    class Fns:
+        def __init__(self, rank):
+            self.rank, self.destroyed = rank, []
+
+        def comm_unique_id(self, ident):
+            ident[0] = 42
+            return 0
+
+        def comm_create(self, ctx, ident, rank, world, comm_ref):
+            assert ident[0] == 42 and world == 2
+            if rank == 1:
+                return 7
+            comm_ref._obj.value = 0xBEEF
+            return 0
+
+        def comm_last_error(self, _):
+            return b"ncclCommInitRank: unhandled system error"
+
+        def comm_destroy(self, comm):
+            self.destroyed.append(comm.value)
+            return 0
+
+        def comm_transport(self, comm):
+            return b"rccl"
+
+    out = {}
+
+    def run(rank):
+        plan = dict(world=2, rank=rank, local_ranks=[rank], devices=[rank], mode="process_per_gpu", rehearsal=False)
+        store = m.FileStore(rank, 2, key="fallback", root=str(tmp_path), timeout=60)
+        fns = Fns(rank)
+        tile = np.full((2, 4, 4), float(rank + 1), np.float32)  # 2 rows of a 4-wide, 4-row frame in 2-row stripes
+        g = m.TileGroup(fns, plan, [C.c_void_p(1)], store, frame=(4, 4, 2), read_tile=lambda k: tile)
+        g.gather()
+        out[rank] = (g.transport, g.host_only, fns.destroyed, g.read_full() if g.is_root else None, g.exchange_ms())
+        store.barrier()
+        store.close()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert set(out) == {0, 1}
+    for rank in (0, 1):
+        transport, host_only, destroyed, full, ms = out[rank]
+        assert host_only and "FALLBACK" in transport and "rank 1" in transport and "okrt_comm_create: status 7" in transport and ms is None
+        assert destroyed == ([0xBEEF] if rank == 0 else [])
+    root = [r for r in (0, 1) if out[r][3] is not None]
+    assert len(root) == 1
+    full = out[root[0]][3]
+    assert full.shape == (4, 4, 4) and (full[:2] == 1.0).all() and (full[2:] == 2.0).all()
