@@ -166,3 +166,25 @@ def test_a_light_in_the_frame_selects_the_full_path_and_the_dark_scene_equals_th
             ort.render()
         frac, rmse, nanmm, _ = compare_accum(acc, ort.ctx.read_accum(), frames=3)
         assert frac >= 0.995 and rmse <= 0.02 and nanmm == 0, (lights, frac, rmse)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_shortcut_equals_full_shading_on_random_scenes(case):
+    """The same property over scenes nobody arranged: random object counts, tessellations, textures, rotations and scales, odd frame sizes that
+    leave partly filled 8x8 tiles, a striped tile now and then, 1-4 bounces, batches and single calls — shortcut on and off, bit for bit."""
+    rng = np.random.default_rng(500 + case)
+    kw = dict(seed=int(rng.integers(1, 10**6)), n_objects=int(rng.integers(1, 9)), detail=int(rng.integers(3, 12)), with_textures=bool(rng.integers(0, 2)),
+              with_lights=False, transforms=bool(rng.integers(0, 2)))
+    if kw["transforms"] and rng.integers(0, 2):
+        kw["scales"] = [float(rng.uniform(1.0, 2.5)) for _ in range(3)]
+    W, H = int(rng.integers(17, 260)), int(rng.integers(9, 150))
+    rt, _, _ = scenes.instantiate(dark_scene(**kw), W, H)
+    rt.ctx.set_option(abi.OPT_MAX_BOUNCES, int(rng.integers(1, 5)))
+    if rng.integers(0, 3) == 0:
+        n = int(rng.integers(2, 4))
+        rt.ctx.set_tile(8, int(rng.integers(0, n)), n)
+    how, frames = ("frames", int(rng.integers(1, 9))) if rng.integers(0, 2) else ("calls", int(rng.integers(1, 4)))
+    (a_on, r_on), (a_off, r_off) = render_both(rt, frames, how)
+    assert flags(rt) & abi.BUILD_FLAG_DARK_MATERIALS
+    assert np.array_equal(a_on, a_off, equal_nan=True) and np.array_equal(r_on, r_off), (kw, W, H, how, frames)
+    rt.close()
