@@ -705,3 +705,42 @@ def test_longest_first_tile_order_leaves_the_picture_alone(tmp_path):
     for k in a.files:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
     assert (a["arr_0"][..., 3] == 42).all()
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_tile_split_and_batching_leave_random_scenes_bit_identical(case):
+    """The two invariances every multi-GPU and every batched run rests on, over scenes nobody arranged: the rows of an N-way striped split
+    equal the full frame's rows, and K frames in one okrt_render_frames equal K okrt_render calls — odd frame sizes (partly filled 8x8
+    tiles, a last stripe that is cut short), lit and unlit scenes (with and without the last-segment shortcut), 0-4 bounces, both builders."""
+    rng = np.random.default_rng(900 + case)
+    kw = dict(seed=int(rng.integers(1, 10**6)), n_objects=int(rng.integers(1, 8)), detail=int(rng.integers(3, 11)), with_textures=bool(rng.integers(0, 2)),
+              with_lights=bool(rng.integers(0, 2)), transforms=bool(rng.integers(0, 2)))
+    desc = scenes.small_mesh_scene(**kw)
+    if rng.integers(0, 2):  # no emitter: with no lights either the last-segment shortcut is taken
+        for e in desc.entities:
+            e.material = {k: v for k, v in e.material.items() if k not in ("emissionColour", "emissionPower")}
+    W, H = int(rng.integers(20, 300)), int(rng.integers(17, 170))
+    bounces, frames, n = int(rng.integers(0, 5)), int(rng.integers(2, 7)), int(rng.integers(2, 5))
+    stripe = int(rng.choice([8, 16]))
+    builder = abi.BUILDER_DEVICE if rng.integers(0, 2) else abi.BUILDER_HOST
+    rt, _, _ = scenes.instantiate(desc, W, H)
+    rt.ctx.set_option(abi.OPT_MAX_BOUNCES, bounces)
+    rt.ctx.set_option(abi.OPT_BUILDER, builder)
+    rt.renderFrames(frames)
+    full = rt.ctx.read_accum()
+    rt.resetAccumulation()
+    for _ in range(frames):
+        rt.render()
+    assert np.array_equal(rt.ctx.read_accum(), full, equal_nan=True), (kw, W, H, bounces, frames)
+    tiles = []
+    for r in range(n):
+        rt.ctx.set_tile(stripe, r, n)
+        rt.resetAccumulation()
+        rt.renderFrames(frames)
+        t = rt.ctx.read_accum()
+        rows = tiling.owned_rows(H, stripe, r, n)
+        assert t.shape[0] >= len(rows)
+        tiles.append(t[: len(rows)])
+        assert np.array_equal(t[: len(rows)], full[rows], equal_nan=True), (kw, W, H, bounces, frames, n, stripe, r)
+    assert np.array_equal(tiling.deinterleave(tiles, H, stripe), full, equal_nan=True)
+    rt.close()
