@@ -16,7 +16,7 @@ for wl in ("sponza","dragon","dragon8m","dragon80k","glass"):
             print(wl, pk, "no line", e); continue
         r=d["roofline"]; ks=r["kernels"]
         cam=ks[0]["ms_per_frame"] if ks else 0
-        tr=sum(k["ms_per_frame"] for k in ks if k["kernel"].startswith("traceKernel"))
+        tr=sum(k["ms_per_frame"] for k in ks[1:] if k["kernel"].startswith("traceKernel"))  # (ks[0] is the camera segment: "traceKernelCamera + ..." when it runs per ray)
         sh=sum(k["ms_per_frame"] for k in ks if k["kernel"].startswith(("missKernel","shadeKernel")))
         print(f"{wl:10s} {'packet' if pk else 'per-ray':8s} {d['ms_per_step']:9.4f} {cam:13.4f} {tr:12.4f} {sh:11.4f} {r['tri48_tests_per_camera_tile']:12.2f} {r['tri48_tests_per_bounce_ray']:14.2f}")
 PY
