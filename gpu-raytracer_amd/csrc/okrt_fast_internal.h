@@ -128,9 +128,14 @@ OKRT_DEV bool shadeSegment(const SceneView& s, const okrt_render_data& rd, Ray& 
     return bounce < lastBounce;
 }
 
-// Does a triangle hit at distance d replace the current closest hit? Nearer wins (RaytracerCS.hlsl:316: strict <); among
-// equal distances the first one met stays (each kernel's visit order is deterministic per ray).
-OKRT_DEV bool closerHit(float d, uint32_t, uint32_t, float best, uint32_t, uint32_t) { return d < best; }
+// Does a triangle hit at distance d replace the current closest hit (packet kernel, known-answer probe)? Nearer wins
+// (RaytracerCS.hlsl:316: strict <); among EQUAL distances the lower triangle index does, whatever the visit order: a packet tests
+// the union of its rays' leaves in the packet's order, and a ray must not find another triangle because it shares its packet with
+// other rays (frame-stacked packets regroup the same rays by launch-set size). The reference keeps the first one met in ITS order;
+// either rule differs from it on exact ties only (tests: "up to equal-distance ties").
+OKRT_DEV bool closerHit(float d, uint32_t tri, uint32_t idx, float best, uint32_t bestTri, uint32_t bestIdx) {
+    return d < best || (d == best && (tri < bestTri || (tri == bestTri && idx < bestIdx)));  // (two instances of one mesh share triangle indices)
+}
 
 // primary ray index -> pixel (8x8 tiles, row-major over tiles)
 OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t& lrow) {
@@ -162,6 +167,9 @@ struct FusedArgs {
     const uint32_t* tileOrder;
     uint32_t* tileCost;
     uint32_t frames;
+    // 1 = every full group of four of a tile's `frames` packets is cut as 4x4 pixels x 4 consecutive frames instead of 8x8 pixels x 1
+    // frame (tracePacketKernel: "frame-stacked packets"); the queue positions, shard counts and the tile order are the same either way
+    uint32_t stackFrames;
 };
 
 // ---- launch wrappers (one per kernel family; `count` selects the variant that feeds okrt_counters) --------------------

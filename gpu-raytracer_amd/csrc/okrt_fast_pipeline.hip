@@ -529,10 +529,13 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
     // camera tiles longest first (fused packet kernel only; OKRT_FAST_LPT=0 keeps the frame-major order)
     static const bool envLpt = !getenv("OKRT_FAST_LPT") || atoi(getenv("OKRT_FAST_LPT")) != 0;
     const bool lpt = envLpt && packet && envFused;
+    // frame-stacked camera packets (tracePacketKernel; OKRT_FAST_STACK=0 keeps every packet one 8x8 tile of one frame)
+    static const bool envStack = !getenv("OKRT_FAST_STACK") || atoi(getenv("OKRT_FAST_STACK")) != 0;
+    const uint32_t stackDepth = (lpt && envStack && frames >= 4u) ? 1u : 0u;
     const uint32_t tilesPerFrame = perFrame >> 6;
     if (lpt) launchOrderTiles(stream, fs.tileCost, tilesPerFrame, frames, ls.tileOrder, ls.tileOrder + tilesPerFrame, ls.counts);
     const FusedArgs fa{perFrame, ls.q[1], ls.counts + kShards * kCursorStride, lastBounce, accum, result, radiance, ls.rdDev, (terminal && lastBounce == 1) ? 1u : 0u,
-                       lpt ? ls.tileOrder : nullptr, lpt ? fs.tileCost : nullptr, frames};
+                       lpt ? ls.tileOrder : nullptr, lpt ? fs.tileCost : nullptr, frames, stackDepth};
     const ShardView cameraShards = lpt ? ShardView{cap, 0u, envBatch, envAffinity, ls.counts, ls.counts + kCursorBase} : shards(0, true);
     const uint32_t pixels32 = (uint32_t)pixels;
     // the one step of a launch set that touches the accumulation: after the previous set's (another stream may carry it)

@@ -466,6 +466,18 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 const uint32_t tileIdx = fa.tileOrder[rk * kShards + s_];
                 ii = (tileIdx << 6) + lane;
                 if (f == 0u) costTile = tileIdx;
+                if (fa.stackFrames && f < (fa.frames & ~3u)) {
+                    // frame-stacked packets: of the tile's `frames` packets, every full group of four is cut as 4x4 pixels x 4 frames instead
+                    // of 8x8 pixels x 1 frame — packet number f is quadrant (f & 3) of the tile in frames (f & ~3) .. + 3; what is left over
+                    // (frames % 4 packets) stays 8x8. The four rays of a pixel differ by their jitter only, so such a packet's footprint is a
+                    // quarter of a tile's and it enters fewer boxes and leaves (Sponza: camera kernel -8 %, 871 k dragon -24 %; 2x2 x 16
+                    // gains more here and loses it in missKernel's scattered slot writes, LABNOTES r05). Which rays share a packet cannot
+                    // change a ray's hit: nearest wins, equal distances go to the lower triangle index (closerHit), so a frame is the same
+                    // picture in a set of one and in a set of twenty.
+                    const uint32_t qd = f & 3u, lx = (lane & 3u) + 4u * (qd & 1u), ly = ((lane >> 2) & 3u) + 4u * (qd >> 1);
+                    ii = (tileIdx << 6) + ly * 8u + lx;
+                    f = (f & ~3u) + (lane >> 4);
+                }
             } else {
                 f = mine / fa.perFrame;
                 ii = mine - f * fa.perFrame;

@@ -86,7 +86,7 @@ def test_roofline_report_is_a_fraction_and_names_its_basis(monkeypatch):
     bounce = rays - px
     assert tk["algorithmic_bytes_per_launch"] == int((32 * bounce + 4 * (90_000 - 43_000)) * 64 + 64 * 65_500 + 48 * 262_267)
     assert tk["bound"] == "valu-issue" and tk["valu_issue_frac"] == 1.19 and tk["wait_mem_share"] == 0.46 and rep["binding_resource"] == "valu-issue"
-    assert rep["kernels"][2]["bound"].startswith("fabric") and rep["bound"] == "hbm" and rep["camera_segment"] == "8x8 packets"
+    assert rep["kernels"][2]["bound"].startswith("fabric") and rep["bound"] == "hbm" and rep["camera_segment"].startswith("packets of 64 rays")
     rep = bench.roofline_report(args, 1, False, [12.7, 0.01, 17.5, 1.6], 1, 64, dict(build, flags=4 | 8), ref, fast, cam, 117.9e9, 1e9, 0.47, 0.095, 0.0, True)
     assert rep["kernels"][0]["kernel"].startswith("traceKernelCamera") and rep["camera_segment"] == "per ray (probe)"
 

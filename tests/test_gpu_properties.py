@@ -674,8 +674,11 @@ def test_a_granted_reservation_leaves_larger_launch_sets_alone():
 def test_longest_first_tile_order_leaves_the_picture_alone(tmp_path):
     """Round 5: the fused camera kernel issues its 8x8 tiles in descending order of the steps they took in the previous launch set
     (okrt_fast_shade.hip: orderTilesKernel). The order is read from the environment once per process (OKRT_FAST_LPT), so the two
-    pictures come from two processes: accumulation and resolve after a mix of launch shapes must be the same bytes, through a
-    striped tile as well (a rank's share: the shards are short there)."""
+    pictures come from separate processes: accumulation and resolve after a mix of launch shapes must be the same bytes, through a
+    striped tile as well (a rank's share: the shards are short there). The same kernel cuts every full group of four of a tile's
+    packets as 4x4 pixels x 4 frames (frame-stacked packets, OKRT_FAST_STACK; off with the order): the launch shapes below give
+    sets of 1, 3, 7 and 20 frames — no group, none, one group + three plain packets, five groups — and the third process keeps the
+    order but not the stacking. Which rays share a packet must not change a single byte."""
     import subprocess
     import sys
     code = (
@@ -694,16 +697,17 @@ def test_longest_first_tile_order_leaves_the_picture_alone(tmp_path):
         "np.savez(sys.argv[1], *out)\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = []
-    for lpt in ("1", "0"):
-        path = str(tmp_path / f"lpt{lpt}.npz")
-        env = dict(os.environ, OKRT_FAST_LPT=lpt)
+    for tag, extra in (("default", {}), ("frame_major", {"OKRT_FAST_LPT": "0"}), ("unstacked", {"OKRT_FAST_STACK": "0"})):
+        path = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         files.append(np.load(path))
-    a, b = files
+    a = files[0]
     assert len(a.files) == 4
-    for k in a.files:
-        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for b in files[1:]:
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
     assert (a["arr_0"][..., 3] == 42).all()
 
 
