@@ -335,7 +335,7 @@ def roofline_report(args, world, samples_split, interval_ms, launches, frames, b
         "node4q_visits_per_bounce_ray": round(b_nodes / max(bounce_rays, 1), 2), "tri48_tests_per_bounce_ray": round(b_tris / max(bounce_rays, 1), 2),
         # (wave-level counts under the packet kernel, per packet of 64 rays; under the per-ray camera kernel the same expression is the average per RAY)
         "node4q_steps_per_camera_tile": round(cam_nodes / 64 / max(pixels / 64, 1), 2), "tri48_tests_per_camera_tile": round(cam_tris / 64 / max(pixels / 64, 1), 2),
-        "camera_segment": "per ray (probe)" if build.get("flags", 0) & 8 else "packets of 64 rays: 4x4 pixels x 4 frames (8x8 x 1 for what a launch set has beyond a multiple of four frames)",
+        "camera_segment": "per ray (probe)" if build.get("flags", 0) & 8 else "packets of 64 rays: 4x2 pixels x 8 frames (4x4 x 4, then 8x8 x 1, for what a launch set has beyond a multiple of eight / four frames)",
         "structure_bytes": structure_bytes,
         "traversal_ms_per_frame": round(trace_ms_frame, 4), "later_shading_ms_per_frame": round(shade_ms_frame, 4), "other_ms_per_frame": round(other_ms_frame, 4),
         # SURVEY.md §8d to the letter, kept under its own name: the bytes the REFERENCE's octree -> mesh -> BVH order would touch
@@ -468,8 +468,9 @@ def main():
 
     # ---- roofline numerator: the reference-order counters of one frame of this workload -------
     def counted(st, traversal, max_bounces, frames=1):
-        """okrt_counters of `frames` frames in one launch set, per frame. The fast pipeline is counted over FOUR frames: from four frames
-        on its camera kernel cuts packets as 4x4 pixels x 4 frames (frame-stacked packets), which is the shape the timed region runs."""
+        """okrt_counters of `frames` frames in one launch set, per frame. The fast pipeline is counted over EIGHT frames: its camera kernel
+        cuts a launch set's packets as 4x2 pixels x 8 frames (frame-stacked packets; 4x4 x 4 and 8x8 x 1 for what is left beyond a multiple
+        of eight / four frames), which is the shape most of the timed region runs."""
         st.ctx.set_option(abi.OPT_TRAVERSAL, traversal)
         st.ctx.set_option(abi.OPT_MAX_BOUNCES, max_bounces)
         st.rt.resetAccumulation()
@@ -484,9 +485,9 @@ def main():
     for st in ranks:
         st.ctx.set_option(abi.OPT_COUNTERS, 1)
     ref_counters = add_counters([counted(st, abi.TRAVERSAL_REFERENCE, args.max_bounces) for st in ranks])
-    fast_counters = add_counters([counted(st, abi.TRAVERSAL_FAST, args.max_bounces, 4) for st in ranks])  # its own node / triangle visit counts, same frame indices
+    fast_counters = add_counters([counted(st, abi.TRAVERSAL_FAST, args.max_bounces, 8) for st in ranks])  # its own node / triangle visit counts, same frame indices
     # the camera segment alone (max_bounces = 0): splits the node / triangle visit counts between the two traversal kernels
-    camera_counters = add_counters([counted(st, abi.TRAVERSAL_FAST, 0, 4) for st in ranks])
+    camera_counters = add_counters([counted(st, abi.TRAVERSAL_FAST, 0, 8) for st in ranks])
     for st in ranks:
         st.ctx.set_option(abi.OPT_MAX_BOUNCES, args.max_bounces)
         st.ctx.set_option(abi.OPT_COUNTERS, 0)

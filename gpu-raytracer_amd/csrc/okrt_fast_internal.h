@@ -167,8 +167,9 @@ struct FusedArgs {
     const uint32_t* tileOrder;
     uint32_t* tileCost;
     uint32_t frames;
-    // 1 = every full group of four of a tile's `frames` packets is cut as 4x4 pixels x 4 consecutive frames instead of 8x8 pixels x 1
-    // frame (tracePacketKernel: "frame-stacked packets"); the queue positions, shard counts and the tile order are the same either way
+    // 1 = of a tile's `frames` packets every full group of eight is cut as 4x2 pixels x 8 consecutive frames, every full group of four
+    // of the rest as 4x4 pixels x 4 frames, instead of 8x8 pixels x 1 frame (tracePacketKernel: "frame-stacked packets"); the queue
+    // positions, shard counts and the tile order are the same either way
     uint32_t stackFrames;
 };
 

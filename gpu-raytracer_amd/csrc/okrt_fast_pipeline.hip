@@ -290,8 +290,10 @@ void fastDestroy(FastScene* fs) {
 //     packet   = 130 per node step + 95 per triangle test                        (counted per wave)
 //     per ray  = (125 per node visit + 95 per triangle test) / 0.5 lanes + 1500  (counted per lane; 1500 = the unfused segment's
 //                generate, hit-record and separate shading traffic, from the same table)
-// The per-ray kernel is taken when its cost is below 0.8 of the packet's (model / measured per-ray : packet ratios on the five
-// workloads: 0.35 / 0.52, 0.98 / 1.13, 2.1 / 1.7, 3.9 / 1.5, 1.7 / 1.5). The counts are deterministic, so the choice is; OKRT_FAST_PACKET=0/1 in the environment overrides it. Closest hits agree bit
+// The per-ray kernel is taken when its cost is below 0.7 of the packet's (model / measured per-ray : packet ratios on the five
+// workloads: 0.35 / 0.52, 0.98 / 1.13, 2.1 / 1.7, 3.9 / 1.5, 1.7 / 1.5 with 8x8 packets; the probe counts 8x8 packets of ONE frame,
+// and the frame-stacked packets a launch set of four or more frames is cut into take 15-30 % fewer steps — measured per-ray : stacked
+// packet 0.64 / 1.6 / 1.6 / 1.5 / 1.7 — which is why the margin is 0.7 and not 0.8). The counts are deterministic, so the choice is; OKRT_FAST_PACKET=0/1 in the environment overrides it. Closest hits agree bit
 // for bit between the two (same arithmetic per lane); only equal-distance ties may pick another triangle.
 namespace {
 bool cameraUsesPacket(const FastScene& fs) {
@@ -360,7 +362,7 @@ bool probeCameraSegment(FastScene& fs, const SceneView& s, const okrt_render_dat
     pr.rayTriTestsPerRay = (float)(host[kNumCounters + 11] / rays);
     pr.packetCost = 130.f * pr.packetNodeStepsPerTile + 95.f * pr.packetTriTestsPerTile;
     pr.perRayCost = (125.f * pr.rayNodeVisitsPerRay + 95.f * pr.rayTriTestsPerRay) / 0.5f + 1500.f;
-    fs.cameraPacket = pr.perRayCost < 0.8f * pr.packetCost ? 0 : 1;  // (a margin: on the 871 k-triangle scene the model says 0.98, the clock 1.13)
+    fs.cameraPacket = pr.perRayCost < 0.7f * pr.packetCost ? 0 : 1;  // (a margin: on the 871 k-triangle scene the model says 0.98, the clock 1.13 — 1.6 with stacked packets)
     pr.chosePacket = (uint32_t)fs.cameraPacket;
     if (getenv("OKRT_FAST_PROBE_PRINT"))  // developer knob: the numbers behind the choice
         fprintf(stderr, "[okrt] camera-segment probe: %u tiles; packet %.2f node steps + %.2f triangle tests per tile = %.0f; per ray %.2f node visits + %.2f "

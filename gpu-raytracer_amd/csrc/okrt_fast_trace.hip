@@ -466,17 +466,25 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                 const uint32_t tileIdx = fa.tileOrder[rk * kShards + s_];
                 ii = (tileIdx << 6) + lane;
                 if (f == 0u) costTile = tileIdx;
-                if (fa.stackFrames && f < (fa.frames & ~3u)) {
-                    // frame-stacked packets: of the tile's `frames` packets, every full group of four is cut as 4x4 pixels x 4 frames instead
-                    // of 8x8 pixels x 1 frame — packet number f is quadrant (f & 3) of the tile in frames (f & ~3) .. + 3; what is left over
-                    // (frames % 4 packets) stays 8x8. The four rays of a pixel differ by their jitter only, so such a packet's footprint is a
-                    // quarter of a tile's and it enters fewer boxes and leaves (Sponza: camera kernel -8 %, 871 k dragon -24 %; 2x2 x 16
-                    // gains more here and loses it in missKernel's scattered slot writes, LABNOTES r05). Which rays share a packet cannot
-                    // change a ray's hit: nearest wins, equal distances go to the lower triangle index (closerHit), so a frame is the same
-                    // picture in a set of one and in a set of twenty.
-                    const uint32_t qd = f & 3u, lx = (lane & 3u) + 4u * (qd & 1u), ly = ((lane >> 2) & 3u) + 4u * (qd >> 1);
-                    ii = (tileIdx << 6) + ly * 8u + lx;
-                    f = (f & ~3u) + (lane >> 4);
+                if (fa.stackFrames) {
+                    // frame-stacked packets: of the tile's `frames` packets, every full group of EIGHT is cut as 4x2 pixels x 8 frames and
+                    // every full group of FOUR of the rest as 4x4 pixels x 4 frames, instead of 8x8 pixels x 1 frame; what is left over
+                    // (frames % 4 packets) stays 8x8. The rays of a pixel differ by their jitter only, so such a packet's footprint is an
+                    // eighth / a quarter of a tile's and it enters fewer boxes and leaves (64-frame sets, 8x8x1 / 4x4x4 / 4x2x8: Sponza
+                    // camera kernel 0.169 / 0.155 / 0.150 ms per frame, 871 k dragon 0.086 / 0.066 / 0.061; 2x2x16 gains more here and loses
+                    // it in missKernel's scattered slot writes, LABNOTES r05). Which rays share a packet cannot change a ray's hit: nearest
+                    // wins, equal distances go to the lower triangle index (closerHit), so a frame is the same picture in a set of one and
+                    // in a set of twenty.
+                    const uint32_t eights = fa.frames & ~7u;
+                    if (f < eights) {
+                        const uint32_t sb = f & 7u, lx = (lane & 3u) + 4u * (sb & 1u), ly = ((lane >> 2) & 1u) + 2u * (sb >> 1);
+                        ii = (tileIdx << 6) + ly * 8u + lx;
+                        f = (f & ~7u) + (lane >> 3);
+                    } else if (f < (fa.frames & ~3u)) {
+                        const uint32_t qd = f & 3u, lx = (lane & 3u) + 4u * (qd & 1u), ly = ((lane >> 2) & 3u) + 4u * (qd >> 1);
+                        ii = (tileIdx << 6) + ly * 8u + lx;
+                        f = (f & ~3u) + (lane >> 4);
+                    }
                 }
             } else {
                 f = mine / fa.perFrame;

@@ -675,10 +675,10 @@ def test_longest_first_tile_order_leaves_the_picture_alone(tmp_path):
     """Round 5: the fused camera kernel issues its 8x8 tiles in descending order of the steps they took in the previous launch set
     (okrt_fast_shade.hip: orderTilesKernel). The order is read from the environment once per process (OKRT_FAST_LPT), so the two
     pictures come from separate processes: accumulation and resolve after a mix of launch shapes must be the same bytes, through a
-    striped tile as well (a rank's share: the shards are short there). The same kernel cuts every full group of four of a tile's
-    packets as 4x4 pixels x 4 frames (frame-stacked packets, OKRT_FAST_STACK; off with the order): the launch shapes below give
-    sets of 1, 3, 7 and 20 frames — no group, none, one group + three plain packets, five groups — and the third process keeps the
-    order but not the stacking. Which rays share a packet must not change a single byte."""
+    striped tile as well (a rank's share: the shards are short there). The same kernel cuts every full group of eight of a tile's
+    packets as 4x2 pixels x 8 frames and every full group of four of the rest as 4x4 x 4 (frame-stacked packets, OKRT_FAST_STACK;
+    off with the order): the launch shapes below give sets of 1, 7, 13 and 11 frames — plain 8x8 packets; 4 + 3 plain; 8 + 4 + 1;
+    8 + 3 plain — and the third process keeps the order but not the stacking. Which rays share a packet must not change a byte."""
     import subprocess
     import sys
     code = (
@@ -689,7 +689,7 @@ def test_longest_first_tile_order_leaves_the_picture_alone(tmp_path):
         "for tile in (None, (8, 1, 3)):\n"
         "    rt, _, _ = scenes.instantiate(scenes.small_mesh_scene(seed=11, n_objects=6, detail=9), 320, 200)\n"
         "    if tile: rt.ctx.set_tile(*tile)\n"
-        "    for m in (1, 7, 1, 1, 20, 3):\n"
+        "    for m in (1, 7, 1, 13, 11):\n"
         "        rt.renderFrames(m)\n"
         "    for _ in range(9): rt.render()\n"
         "    out += [rt.ctx.read_accum(), rt.ctx.read_result().astype(np.float32)]\n"
