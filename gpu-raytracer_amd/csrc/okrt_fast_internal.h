@@ -137,6 +137,23 @@ OKRT_DEV bool closerHit(float d, uint32_t tri, uint32_t idx, float best, uint32_
     return d < best || (d == best && (tri < bestTri || (tri == bestTri && idx < bestIdx)));  // (two instances of one mesh share triangle indices)
 }
 
+// Frame-stacked packets: packet number p (0 .. frames-1) of 8x8 tile `tileIdx`, lane l -> (ii = the lane's pixel as an index into
+// the 8x8-tiled frame, f = its frame). Of the tile's `frames` packets every full group of EIGHT is cut as 4x2 pixels x 8 frames, every
+// full group of FOUR of the rest as 4x4 pixels x 4 frames, and what is left over (frames % 4 packets) stays 8x8 pixels x 1 frame.
+OKRT_DEV void stackedPacketLane(uint32_t frames, uint32_t p, uint32_t lane, uint32_t tileIdx, uint32_t& ii, uint32_t& f) {
+    ii = (tileIdx << 6) + lane;
+    f = p;
+    if (p < (frames & ~7u)) {
+        const uint32_t sb = p & 7u, lx = (lane & 3u) + 4u * (sb & 1u), ly = ((lane >> 2) & 1u) + 2u * (sb >> 1);
+        ii = (tileIdx << 6) + ly * 8u + lx;
+        f = (p & ~7u) + (lane >> 3);
+    } else if (p < (frames & ~3u)) {
+        const uint32_t qd = p & 3u, lx = (lane & 3u) + 4u * (qd & 1u), ly = ((lane >> 2) & 3u) + 4u * (qd >> 1);
+        ii = (tileIdx << 6) + ly * 8u + lx;
+        f = (p & ~3u) + (lane >> 4);
+    }
+}
+
 // primary ray index -> pixel (8x8 tiles, row-major over tiles)
 OKRT_DEV bool primaryPixel(const TileView& t, uint32_t i, uint32_t& px, uint32_t& lrow) {
     const uint32_t tilesX = (t.W + 7) >> 3;
@@ -174,7 +191,9 @@ struct FusedArgs {
 };
 
 // ---- launch wrappers (one per kernel family; `count` selects the variant that feeds okrt_counters) --------------------
-void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames);
+// (stacked = 1: positions are tile-major, `frames` packets per tile cut by stackedPacketLane — what the camera-segment probe traces)
+void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames,
+                    uint32_t stacked = 0);
 void launchTrace(bool count, int mode, dim3 grid, hipStream_t stream, const FastView& fv, const SceneView& s, const okrt_render_data& rd, const TileView& tile,
                  RayQueue q, HitBuffer hb, const ShardView& sv, uint32_t cameraFrames, unsigned long long* counters, unsigned long long* rayTotals);
 void launchPacket(bool count, bool fused, dim3 grid, hipStream_t stream, const uint4* nodes, const float4* tris, const SceneView& s,

@@ -282,19 +282,24 @@ void fastDestroy(FastScene* fs) {
 // ---- camera segment: packet or per-ray, per scene ------------------------------------------------------------------------
 // The packet kernel walks the UNION of its 64 rays' nodes and leaves once per wave; the per-ray kernel walks every ray's own
 // path at 40-60 % lane utilisation and pays the generate / hit-record / shade round trip through HBM. Which is cheaper depends
-// on the scene (r05 table, profiles/r05_packet_vs_per_ray.txt: the packet wins 1.5x on the Sponza-class scene, loses 1.9x on
-// 8 M sub-pixel triangles, where a tile's union is 105 triangle tests against 5 per ray). So the first launch set after a build
-// PROBES: about eight 8-row stripes spread over the FULL frame (not the context's own tile: every rank of a split decides alike,
-// and like a single-GPU context) are traced by the counting variants of both kernels, and a cost model in VALU wave-instructions
-// per tile — the unit both kernels are bound by (roofline.kernels[].valu_issue_frac) — picks one:
+// on how far a packet's rays spread over the scene's triangles (profiles/r05_packet_vs_per_ray.txt). With 8x8-pixel packets of
+// one frame the packet won 1.5x on the Sponza-class scene and LOST 1.9x on 8 M sub-pixel triangles (a tile's union: 105 triangle
+// tests against 5 per ray); with the frame-stacked packets a launch set is cut into (4x2 pixels x 8 frames: 28 tests) it wins on
+// all five workloads, by 1.3x on that one. So the first launch set after a build PROBES: about eight 8-row stripes spread over the
+// FULL frame (not the context's own tile: every rank of a split decides alike, and like a single-GPU context), EIGHT frames of
+// them cut into stacked packets (generateKernel, stacked order), are traced by the counting variants of both kernels, and a cost
+// model in VALU wave-instructions per packet of 64 rays — the unit both kernels are bound by (roofline.kernels[].valu_issue_frac)
+// — picks one:
 //     packet   = 130 per node step + 95 per triangle test                        (counted per wave)
 //     per ray  = (125 per node visit + 95 per triangle test) / 0.5 lanes + 1500  (counted per lane; 1500 = the unfused segment's
 //                generate, hit-record and separate shading traffic, from the same table)
-// The per-ray kernel is taken when its cost is below 0.7 of the packet's (model / measured per-ray : packet ratios on the five
-// workloads: 0.35 / 0.52, 0.98 / 1.13, 2.1 / 1.7, 3.9 / 1.5, 1.7 / 1.5 with 8x8 packets; the probe counts 8x8 packets of ONE frame,
-// and the frame-stacked packets a launch set of four or more frames is cut into take 15-30 % fewer steps — measured per-ray : stacked
-// packet 0.64 / 1.6 / 1.6 / 1.5 / 1.7 — which is why the margin is 0.7 and not 0.8). The counts are deterministic, so the choice is; OKRT_FAST_PACKET=0/1 in the environment overrides it. Closest hits agree bit
-// for bit between the two (same arithmetic per lane); only equal-distance ties may pick another triangle.
+// The per-ray kernel is taken when its cost is below 0.7 of the packet's: a margin, because the model leans towards the per-ray
+// kernel where it matters (model / measured per-ray : packet on dragon8m, dragon, dragon80k, glass, sponza: 0.98 / 1.31,
+// 1.85 / 1.73, 2.8 / 1.66, 4.5 / 1.49, 2.1 / 1.74). One choice per scene, made for the stacked shape (every launch set of eight
+// frames or more is mostly that; okrt_render defers and batches 16 by default): switching kernels with the set size would let
+// equal-distance ties fall differently from set to set. The counts are deterministic, so the choice is; OKRT_FAST_PACKET=0/1 in
+// the environment overrides it. Closest hits agree bit for bit between the two kernels (same arithmetic per lane); only
+// equal-distance ties may pick another triangle.
 namespace {
 bool cameraUsesPacket(const FastScene& fs) {
     static const int envPacket = getenv("OKRT_FAST_PACKET") ? atoi(getenv("OKRT_FAST_PACKET")) : -1;
@@ -314,7 +319,9 @@ bool probeCameraSegment(FastScene& fs, const SceneView& s, const okrt_render_dat
     for (uint32_t k = pt.stripeIndex; k * 8 < H; k += stride) pt.rows += std::min(8u, H - k * 8);
     if (!pt.rows) return true;
     const uint32_t perFrame = (((W + 7) >> 3) * ((pt.rows + 7) >> 3)) << 6;
-    const uint32_t cap = (((perFrame + kShards - 1) / kShards + 255) / 256) * 256;
+    constexpr uint32_t kProbeFrames = 8;  // eight frames of the stripes, as packets of 4x2 pixels x 8 frames: what a launch set is mostly cut into
+    const uint32_t positions = perFrame * kProbeFrames;
+    const uint32_t cap = (((positions + kShards - 1) / kShards + 255) / 256) * 256;
     const size_t items = (size_t)cap * kShards;
     RayQueue q{};
     HitBuffer hb{};
@@ -338,11 +345,11 @@ bool probeCameraSegment(FastScene& fs, const SceneView& s, const okrt_render_dat
     if (ok && e == hipSuccess) {
         okrt_render_data prd = rd;
         const FastView fv{fs.nodes.p, fs.tris.p, overflow, fs.overflowCap, (uint32_t)(fs.numNodes * sizeof(Node4Q)), (uint32_t)(fs.numTris * sizeof(Tri48))};
-        const ShardView sv{cap, perFrame, kBatch, 1u, nullptr, counts + kShards * kCursorStride};
-        launchGenerate(dim3((unsigned)(items / 256)), stream, prd, pt, q, perFrame, 1u);
-        launchPacket(true, false, dim3((unsigned)(fs.cus * 6)), stream, fs.nodes.p, fs.tris.p, s, prd, pt, q, hb, sv, 1u, ctr, ctr, FusedArgs{});
+        const ShardView sv{cap, positions, kBatch, 1u, nullptr, counts + kShards * kCursorStride};
+        launchGenerate(dim3((unsigned)(items / 256)), stream, prd, pt, q, perFrame, kProbeFrames, 1u);
+        launchPacket(true, false, dim3((unsigned)(fs.cus * 6)), stream, fs.nodes.p, fs.tris.p, s, prd, pt, q, hb, sv, kProbeFrames, ctr, ctr, FusedArgs{});
         e = hipMemsetAsync(counts, 0, countWords * sizeof(uint32_t), stream);  // the cursors again, for the second walk over the same rays
-        launchTrace(true, 0, dim3(fs.traceBlocks), stream, fv, s, prd, pt, q, hb, sv, 1u, ctr + kNumCounters, ctr + kNumCounters);
+        launchTrace(true, 0, dim3(fs.traceBlocks), stream, fv, s, prd, pt, q, hb, sv, kProbeFrames, ctr + kNumCounters, ctr + kNumCounters);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(host, ctr, sizeof(host), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -353,16 +360,16 @@ bool probeCameraSegment(FastScene& fs, const SceneView& s, const okrt_render_dat
         err = std::string("camera-segment probe: ") + hipGetErrorString(e);
         return false;
     }
-    const double tiles = perFrame / 64.0, rays = (double)pt.rows * W;
+    const double tiles = positions / 64.0, rays = (double)pt.rows * W * kProbeFrames;  // ("tile" = one packet of 64 rays)
     FastCameraProbe& pr = fs.probe;
-    pr.tiles = perFrame / 64;
+    pr.tiles = positions / 64;
     pr.packetNodeStepsPerTile = (float)(host[10] / 64.0 / tiles);
     pr.packetTriTestsPerTile = (float)(host[11] / 64.0 / tiles);
     pr.rayNodeVisitsPerRay = (float)(host[kNumCounters + 10] / rays);
     pr.rayTriTestsPerRay = (float)(host[kNumCounters + 11] / rays);
     pr.packetCost = 130.f * pr.packetNodeStepsPerTile + 95.f * pr.packetTriTestsPerTile;
     pr.perRayCost = (125.f * pr.rayNodeVisitsPerRay + 95.f * pr.rayTriTestsPerRay) / 0.5f + 1500.f;
-    fs.cameraPacket = pr.perRayCost < 0.7f * pr.packetCost ? 0 : 1;  // (a margin: on the 871 k-triangle scene the model says 0.98, the clock 1.13 — 1.6 with stacked packets)
+    fs.cameraPacket = pr.perRayCost < 0.7f * pr.packetCost ? 0 : 1;  // (a margin: on the 8 M-triangle scene the model says 0.98, the clock 1.31)
     pr.chosePacket = (uint32_t)fs.cameraPacket;
     if (getenv("OKRT_FAST_PROBE_PRINT"))  // developer knob: the numbers behind the choice
         fprintf(stderr, "[okrt] camera-segment probe: %u tiles; packet %.2f node steps + %.2f triangle tests per tile = %.0f; per ray %.2f node visits + %.2f "

@@ -9,10 +9,14 @@ namespace {
 // Camera rays for every owned pixel, in tile order (position i <-> pixel by primaryPixel): origin, direction,
 // RNG state after the 4 camera draws, framebuffer offset. Padding positions (outside the image) get pix = kInvalid.
 // With `frames` > 1 the positions of frame f follow those of frame f-1 and pix addresses the frame's radiance slot.
-__global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileView tile, RayQueue q, uint32_t perFrame, uint32_t frames) {
+__global__ __launch_bounds__(256) void generateKernel(okrt_render_data rd, TileView tile, RayQueue q, uint32_t perFrame, uint32_t frames, uint32_t stacked) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= perFrame * frames) return;
-    const uint32_t f = i / perFrame, ii = i - f * perFrame;
+    uint32_t f = i / perFrame, ii = i - f * perFrame;
+    if (stacked) {  // tile-major: the `frames` packets of a tile next to each other, cut like the fused camera kernel cuts them
+        const uint32_t packet = i >> 6, t = packet / frames;
+        stackedPacketLane(frames, packet - t * frames, i & 63u, t, ii, f);
+    }
     uint32_t px, lrow, seed = 0, pix = kInvalid;
     Ray ray;
     ray.origin = ray.direction = mk(0.f, 0.f, 0.f);
@@ -186,8 +190,9 @@ void launchSetRenderData(hipStream_t stream, const okrt_render_data& rd, okrt_re
     hipLaunchKernelGGL(setRenderDataKernel, dim3(1), dim3(64), 0, stream, rd, dst);
 }
 
-void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames) {
-    hipLaunchKernelGGL(generateKernel, grid, dim3(256), 0, stream, rd, tile, q, perFrame, frames);
+void launchGenerate(dim3 grid, hipStream_t stream, const okrt_render_data& rd, const TileView& tile, RayQueue q, uint32_t perFrame, uint32_t frames,
+                    uint32_t stacked) {
+    hipLaunchKernelGGL(generateKernel, grid, dim3(256), 0, stream, rd, tile, q, perFrame, frames, stacked);
 }
 
 void launchShade(bool first, bool count, dim3 grid, hipStream_t stream, const SceneView& s, const okrt_render_data& rd, const TileView& tile,

@@ -475,16 +475,7 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
                     // it in missKernel's scattered slot writes, LABNOTES r05). Which rays share a packet cannot change a ray's hit: nearest
                     // wins, equal distances go to the lower triangle index (closerHit), so a frame is the same picture in a set of one and
                     // in a set of twenty.
-                    const uint32_t eights = fa.frames & ~7u;
-                    if (f < eights) {
-                        const uint32_t sb = f & 7u, lx = (lane & 3u) + 4u * (sb & 1u), ly = ((lane >> 2) & 1u) + 2u * (sb >> 1);
-                        ii = (tileIdx << 6) + ly * 8u + lx;
-                        f = (f & ~7u) + (lane >> 3);
-                    } else if (f < (fa.frames & ~3u)) {
-                        const uint32_t qd = f & 3u, lx = (lane & 3u) + 4u * (qd & 1u), ly = ((lane >> 2) & 3u) + 4u * (qd >> 1);
-                        ii = (tileIdx << 6) + ly * 8u + lx;
-                        f = (f & ~3u) + (lane >> 4);
-                    }
+                    stackedPacketLane(fa.frames, f, lane, tileIdx, ii, f);
                 }
             } else {
                 f = mine / fa.perFrame;
