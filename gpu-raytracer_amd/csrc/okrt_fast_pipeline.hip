@@ -554,7 +554,7 @@ LaunchStatus launchFast(FastScene& fs, const SceneView& s, const okrt_render_dat
         if (order.done && he == hipSuccess) he = hipEventRecord(order.done, stream);
     };
     if (packet && envFused) {
-        // segment 0 in ONE kernel: camera rays are generated, traced as 8x8 packets and shaded by the same wave
+        // segment 0 in ONE kernel: camera rays are generated, traced in packets of 64 (frame-stacked where the set has the frames) and shaded by the same wave
         launchPacket(cnt, true, pg, stream, fs.nodes.p, fs.tris.p, s, rd, t, ls.q[0], ls.hb, cameraShards, frames, counters, rayTotals, fa);
         mark();  // (an empty "shade" interval keeps the trace / shade alternation of the event list)
     } else {

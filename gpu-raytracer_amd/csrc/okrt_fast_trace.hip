@@ -1,6 +1,7 @@
 // okrt_fast_trace.hip — the traversal kernels of the wavefront pipeline (okrt_fast_pipeline.hip has the overview):
 //   traceKernel         per-ray, persistent, one step per lane and iteration: every segment but the camera one
-//   tracePacketKernel   one wave per 8x8 pixel tile; FUSED = the whole camera segment (generate, trace, shade, append)
+//   tracePacketKernel   one wave per packet of 64 camera rays (8x8 pixels of one frame, or 4x2 / 4x4 pixels of eight / four frames);
+//                       FUSED = the whole camera segment (generate, trace, shade, append)
 //   fastKatKernel       one thread per ray, the known-answer probe
 #include "okrt_fast_internal.h"
 
@@ -368,8 +369,9 @@ __global__ __launch_bounds__(kTraceThreads) __attribute__((amdgpu_waves_per_eu(O
 }
 
 // ---- packet traversal of camera rays --------------------------------------------------------------------------------
-// Camera rays arrive one 8x8 pixel tile per 64 consecutive positions, i.e. one tile per wave, and the rays of a tile
-// walk almost the same nodes. So the wave traverses the tree ONCE for all its lanes: the current node is wave-uniform,
+// Camera rays arrive in packets of 64 consecutive positions, one packet per wave — an 8x8 pixel tile of one frame, or, where the
+// launch set has the frames, 4x2 / 4x4 pixels of eight / four consecutive frames (frame-stacked packets: stackedPacketLane) — and
+// the rays of a packet walk almost the same nodes. So the wave traverses the tree ONCE for all its lanes: the current node is wave-uniform,
 // its 64 bytes come through the scalar cache into SGPRs (s_load, no vector-memory gather at all), every lane tests its
 // own ray against the four child boxes, a child is visited when ANY lane enters it (`__ballot`), order = entry
 // distance of the first lane that enters, one shared stack of node references in LDS, no divergent control flow.

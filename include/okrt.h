@@ -355,9 +355,9 @@ typedef struct okrt_build_info {
 /* every uploaded Material (t6, t7) has emission colour * power == (0, 0, 0) and |albedo| <= 1: the material half of the condition
  * under which OKRT_OPT_LAST_SEGMENT_SHORTCUT applies (the other half is a RenderData without lights) */
 #define OKRT_BUILD_FLAG_DARK_MATERIALS 4u
-/* the camera segment of this structure is traced ray by ray instead of one 8x8 pixel packet per wave: chosen by the first launch
+/* the camera segment of this structure is traced ray by ray instead of one packet of 64 camera rays per wave: chosen by the first launch
  * set after a build from a probe of that frame (about eight stripes of the full frame through the counting variants of both
- * kernels; gpu-raytracer_amd/csrc/okrt_fast_pipeline.hip: probeCameraSegment) — scenes of sub-pixel triangles, where a packet
+ * kernels; gpu-raytracer_amd/csrc/okrt_fast_pipeline.hip: probeCameraSegment) — scenes of triangles far below a pixel, where a packet
  * walks the union of 64 rays' leaves. Meaningful after the first fast-traversal render. Same closest hits either way. */
 #define OKRT_BUILD_FLAG_CAMERA_PER_RAY 8u
 okrt_status okrt_get_build_info(okrt_ctx* ctx, okrt_build_info* out);
