@@ -17,7 +17,7 @@ for c in range(cases):
         if rng.integers(0, 2):
             kw["scales"] = [float(rng.uniform(1.0, 2.5)) for _ in range(3)]
     W, H = int(rng.integers(17, 200)), int(rng.integers(9, 120))
-    mb, frames = int(rng.integers(0, 5)), int(rng.integers(1, 4))
+    mb, frames = int(rng.integers(0, 5)), int(rng.choice([1, 2, 3, 4, 5, 9, 12]))  # (from four frames on the camera packets are frame-stacked: 4x4 x 4, 4x2 x 8)
     desc = scenes.small_mesh_scene(**kw)
     dark = bool(rng.integers(0, 2))  # round 5: half of the cases without the emitter, so that scenes without lights take the last-segment shortcut
     if dark:
