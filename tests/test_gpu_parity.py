@@ -125,6 +125,22 @@ def test_fast_equals_reference_order_bit_for_bit(max_bounces):
     assert same.mean() >= 0.999, same.mean()
 
 
+@pytest.mark.parametrize("max_bounces", [0, 2])
+def test_frame_stacked_packets_vs_reference_order_and_oracle(oracle, max_bounces):
+    """Twelve frames in one launch set: the fused camera kernel cuts them as packets of 4x2 pixels x 8 frames and 4x4 x 4 (okrt_fast_internal.h:
+    stackedPacketLane) instead of 8x8 pixels of one frame. The picture must still be the reference-order kernel's up to equal-distance ties
+    (a pixel counts as different if ANY of its twelve frames differs) and the oracle's within the N-frame rule."""
+    desc = scenes.small_mesh_scene(seed=21, n_objects=7, detail=14, with_lights=max_bounces == 0)
+    w, h, n = 288, 168, 12
+    accs = [gpu_render(desc, w, h, frames=n, traversal=t, max_bounces=max_bounces)[0] for t in (abi.TRAVERSAL_REFERENCE, abi.TRAVERSAL_FAST)]
+    same = (accs[0] == accs[1]).all(-1) | (np.isnan(accs[0]).any(-1) & np.isnan(accs[1]).any(-1))
+    assert same.mean() >= 0.995, same.mean()
+    assert (accs[1][..., 3] == n).all()
+    ca = cpu_render(oracle, desc, w, h, frames=n, max_bounces=max_bounces)[0]
+    frac, rmse, nanmm, _ = compare_accum(accs[1], ca, n)
+    assert frac >= 0.97 and rmse <= 0.05 and nanmm == 0, (frac, rmse, nanmm)
+
+
 def test_progressive_accumulation_256spp(oracle):
     desc = scenes.small_mesh_scene(seed=9, with_lights=False)
     w, h, n = 64, 36, 256
